@@ -1,0 +1,209 @@
+/*
+ * rt_amd.h - C-ABI of the MI355X-native per-pixel hot path.
+ *
+ * The reference (DanielBarLev2/Ray-Tracing) has no FFI; the "interface for this
+ * path" is the Python call sequence of main() (ray_tracer.py:20-33) and the
+ * object model it passes around.  Each entry point below names the reference
+ * call it replaces.  Plain C only: pointers + sizes, no C++/torch types, every
+ * function returns 0 on success or a negative rt_status; the message for the
+ * last failure on a context is available through rt_last_error().
+ *
+ * All reference arithmetic is float64 and ids are the reference's
+ * `surface.index`; the ABI keeps both (double / int32).
+ *
+ * The same rt_scene_desc is consumed by the CPU oracle (oracle/oracle.cpp,
+ * test infrastructure only) so that both sides see identical bytes.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_AMD_ABI_VERSION 1
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARG = -1,  /* null pointer, negative count, inconsistent scene */
+    RT_ERR_NO_DEVICE = -2,    /* no HIP device / wrong ordinal */
+    RT_ERR_HIP = -3,          /* a HIP runtime call failed (text in rt_last_error) */
+    RT_ERR_OOM = -4,          /* device allocation failed */
+    RT_ERR_QUEUE_OVERFLOW = -5, /* secondary-ray queues exceeded RT_MAX growth; nothing written */
+    RT_ERR_UNSUPPORTED = -6
+} rt_status;
+
+/* surf_kind values: what sits at list position k of the reference's `surfaces`
+ * list (Parser.py:29,52-63).  Normals and materials are looked up by POSITION
+ * using the hit's id (SurfaceAbs.py:61,83 - SURVEY §8a Q8). */
+enum { RT_SURF_BACKGROUND = 0, RT_SURF_SPHERE = 1, RT_SURF_BOX = 2, RT_SURF_PLANE = 3 };
+
+/*
+ * Flattened scene: what Parser.parse_scene_file (Parser.py:25-71) returns plus
+ * the tree of BSPNode.build_bsp_tree (BSPNode.py:54-121), as SoA float64.
+ * The caller keeps ownership; rt_create copies everything.
+ */
+typedef struct rt_scene_desc {
+    int32_t abi_version;         /* RT_AMD_ABI_VERSION */
+
+    /* surfaces list by position (index 0 is Background in parsed scenes) */
+    int32_t n_surfaces;
+    const int32_t *surf_kind;    /* [n_surfaces] RT_SURF_* */
+    const int32_t *surf_geom;    /* [n_surfaces] row in the sphere/box/plane table, -1 for background */
+    const int32_t *surf_mat;     /* [n_surfaces] SurfaceAbs.get_material_index() (SurfaceAbs.py:38-42) */
+
+    /* Sphere.py:6-8,135-139 */
+    int32_t n_spheres;
+    const double *sph_center;    /* [n_spheres*3] */
+    const double *sph_radius;    /* [n_spheres]   */
+    const double *sph_r2;        /* [n_spheres] radius ** 2 exactly as Python evaluates it (Sphere.py:79) */
+    const int32_t *sph_id;       /* [n_spheres] surface.index */
+
+    /* Cube.py:7-14,89-90 */
+    int32_t n_boxes;
+    const double *box_center;    /* [n_boxes*3] */
+    const double *box_scale;     /* [n_boxes]   */
+    const double *box_lo;        /* [n_boxes*3] position - scale/2 */
+    const double *box_hi;        /* [n_boxes*3] position + scale/2 */
+    const int32_t *box_id;       /* [n_boxes] */
+
+    /* InfinitePlane.py:6-10: normal already normalised, d = -offset/|n|.
+     * Order = order in the root node's inf_plains (BSPNode.py:111), Background excluded. */
+    int32_t n_planes;
+    const double *pln_normal;    /* [n_planes*3] */
+    const double *pln_d;         /* [n_planes]   */
+    const int32_t *pln_id;       /* [n_planes]   */
+    int32_t far_clip;            /* 1 if a Background surface is in the root plane list (Background.py:23) */
+
+    /* Material.py:4-11,23-62; list position == material index */
+    int32_t n_materials;
+    const double *mat_kd;        /* [n_materials*3] */
+    const double *mat_ks;        /* [n_materials*3] */
+    const double *mat_kr;        /* [n_materials*3] */
+    const int32_t *mat_phong;    /* [n_materials] shininess truncated toward zero (Material.py:49,58) */
+    const double *mat_transparency; /* [n_materials] */
+
+    /* Light.py:7-14 */
+    int32_t n_lights;
+    const double *lgt_pos;       /* [n_lights*3] */
+    const double *lgt_color;     /* [n_lights*3] */
+    const double *lgt_spec;      /* [n_lights] specular_intensity */
+    const double *lgt_shadow;    /* [n_lights] shadow_intensity   */
+    const double *lgt_radius;    /* [n_lights] */
+
+    /* BSP tree, DFS pre-order: left child of an internal node i is i+1.
+     * Finite primitives are numbered spheres first, then boxes:
+     * prim p < n_spheres is sphere p, else box p - n_spheres. */
+    int32_t n_nodes;
+    const double *node_lo;       /* [n_nodes*3] small_bound */
+    const double *node_hi;       /* [n_nodes*3] big_bound   */
+    const int32_t *node_right;   /* [n_nodes] index of the right child, -1 for a leaf */
+    const int32_t *node_first;   /* [n_nodes] leaf: first entry in leaf_prim, else -1 */
+    const int32_t *node_count;   /* [n_nodes] leaf: number of entries */
+    int32_t n_leaf_refs;
+    const int32_t *leaf_prim;    /* [n_leaf_refs] primitive numbers in leaf-list order */
+
+    /* Camera.py:5-13 (basis from util.create_orthonormal_basis, util.py:48-75) */
+    double cam_pos[3], cam_x[3], cam_y[3], cam_z[3];
+    double cam_screen_distance, cam_screen_width;
+
+    /* SceneSettings.py:1-5 */
+    double background[3];
+    int32_t sh_rays;             /* root_number_shadow_rays */
+    int32_t rec_max;             /* max_recursions */
+} rt_scene_desc;
+
+#define RT_USE_SCENE_VALUE (-2147483647 - 1)
+
+/* Per-frame parameters.  A frame is W*H pixels; with world > 1 this context
+ * renders only the tiles t (row-major tile index) with t % world == rank and
+ * returns them packed tile after tile (rt_tile_layout describes the order). */
+typedef struct rt_render_params {
+    int32_t width, height;
+    int32_t sh_rays;     /* RT_USE_SCENE_VALUE or an override of root_number_shadow_rays */
+    int32_t rec_max;     /* RT_USE_SCENE_VALUE or an override of max_recursions */
+    int32_t jitter;      /* 0: deviations of Light.py:277-279 forced to zero (deterministic parity mode);
+                            1: counter-based hash, 6 x U(-g,g) per shadow ray */
+    uint32_t seed;
+    int32_t rank, world; /* tile interleave over ranks; 0,1 = whole image */
+    int32_t tile_w, tile_h; /* 0 = default 8x8 */
+    int32_t flags;       /* RT_FLAG_* */
+    int32_t reserved;
+} rt_render_params;
+
+#define RT_FLAG_EXACT_TRAVERSAL 1  /* diagnostic: visit nodes with the reference's float64 slab test only
+                                      (no float32 culling, no pruning); results must be identical */
+
+/* Work counters of the last frame (the Mrays/s numerator counts rays exactly as
+ * the reference issues them to BSPNode.intersect_vectorize). */
+typedef struct rt_stats {
+    int64_t primary_rays, shadow_rays, reflect_rays, transmit_rays;
+    int64_t hits;                /* shaded hits over all levels */
+    int64_t levels;              /* recursion levels that had live rays */
+    int64_t max_queue;           /* largest ray queue of the frame */
+    double ms_total;             /* device time of the frame (HIP events) */
+    double ms_intersect, ms_shadow, ms_shade; /* per kernel family, summed over levels */
+} rt_stats;
+
+typedef struct rt_ctx rt_ctx;
+
+/* Replaces: scene objects living in Python + BSPNode tree (ray_tracer.py:20-22). */
+int rt_create(const rt_scene_desc *scene, int device, rt_ctx **out);
+int rt_destroy(rt_ctx *ctx);
+/* Message for the last failure on ctx (ctx == NULL: last rt_create failure of this thread). */
+const char *rt_last_error(const rt_ctx *ctx);
+int rt_abi_version(void);
+
+/* Number of pixels this rank renders and, optionally, their global pixel index
+ * (row*W + col) in output order.  Pure host arithmetic. */
+int64_t rt_tile_pixels(const rt_render_params *p);
+int rt_tile_layout(const rt_render_params *p, int64_t *pixel_index /* [rt_tile_pixels] */);
+
+/*
+ * Replaces ray_tracer.py:25-33: get_initial_rays (ray_functions.py:7-43) +
+ * ray_tracing(...).clip(0,1) (ray_tracer.py:36-133) + save_image's quantisation
+ * (util.py:94-98).  Host buffers, blocking.  Any output may be NULL.
+ *   rgb_out  [npix*3] float32, clipped to [0,1]
+ *   rgb8_out [npix*3] uint8 = (x*255) truncated
+ *   ids_out  [npix]   int32 primary hit ids (0 = background)
+ * npix = rt_tile_pixels(p); output order = rt_tile_layout (row-major when world == 1).
+ */
+int rt_render(rt_ctx *ctx, const rt_render_params *p, float *rgb_out, uint8_t *rgb8_out, int32_t *ids_out,
+              rt_stats *stats);
+
+/* Same, outputs are DEVICE pointers on ctx's device (any may be NULL) and the
+ * work is only enqueued on `stream` (a hipStream_t, NULL = the context's own
+ * stream); nothing is synchronised.  Used by the bench and the multi-GPU gather. */
+int rt_render_device(rt_ctx *ctx, const rt_render_params *p, float *d_rgb_out, uint8_t *d_rgb8_out,
+                     int32_t *d_ids_out, void *stream);
+/* Wait for the context's stream and fetch the counters of the last frame. */
+int rt_sync_stats(rt_ctx *ctx, rt_stats *stats);
+
+/*
+ * Replaces ray_tracing(rays_sources, rays_directions, ...) (ray_tracer.py:36-133)
+ * for an arbitrary ray batch: rgb_out[n*3] float64, unclipped.  Ray i plays the
+ * role of pixel i for the jitter hash.
+ */
+int rt_trace(rt_ctx *ctx, const rt_render_params *p, const double *origins, const double *directions, int64_t n,
+             double *rgb_out, rt_stats *stats);
+
+/*
+ * Replaces BSPNode.intersect_vectorize (BSPNode.py:201-210): nearest hit of n
+ * rays.  points_out[n*3] float64 (the reference's miss point (1e8,1e8,1e8) when
+ * far_clip, NaN otherwise), ids_out[n] int64 (0 = miss).
+ */
+int rt_intersect(rt_ctx *ctx, const double *origins, const double *directions, int64_t n, double *points_out,
+                 int64_t *ids_out);
+
+/* Rank-0 side of the multi-GPU gather: scatter `world` packed per-rank tile
+ * buffers (device memory, rank r at d_packed + r*stride_bytes) into a row-major
+ * W*H*3 uint8 image on the device. */
+int rt_deinterleave_u8(rt_ctx *ctx, const rt_render_params *p, const uint8_t *d_packed, int64_t stride_bytes,
+                       uint8_t *d_image, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */
