@@ -203,6 +203,27 @@ int rt_intersect(rt_ctx *ctx, const double *origins, const double *directions, i
 int rt_deinterleave_u8(rt_ctx *ctx, const rt_render_params *p, const uint8_t *d_packed, int64_t stride_bytes,
                        uint8_t *d_image, void *stream);
 
+/* Replaces get_initial_rays(camera, W, H) (ray_functions.py:7-43) as a standalone query:
+ * sources_out / directions_out [W*H*3] float64, row-major pixel order (i = row, j = col). */
+int rt_initial_rays(rt_ctx *ctx, int width, int height, double *sources_out, double *directions_out);
+
+/*
+ * Kernel-level entry points (no context): ONE primitive against a ray batch, through the same device
+ * functions the frame kernels use.  params12 = 12 doubles:
+ *   RT_SURF_SPHERE {cx,cy,cz, r**2, r, 0...}   Sphere.intersect_vectorized / calculate_normals (Sphere.py:63-133)
+ *   RT_SURF_BOX    {lo xyz, hi xyz, centre xyz, scale, 0,0}   Cube.intersect_vectorized / calculate_normals
+ *                                                             (Cube.py:78-93,177-207)
+ *   RT_SURF_PLANE  {n xyz (unit), d, 0...}     InfinitePlane.intersect_vectorized (InfinitePlane.py:60-92)
+ * points_out rows are NaN where the ray misses.
+ */
+int rt_unit_prim_intersect(int device, int kind, const double *params12, const double *origins,
+                           const double *directions, int64_t n, double *points_out);
+int rt_unit_prim_normals(int device, int kind, const double *params12, const double *points, int64_t n,
+                         double *normals_out);
+/* Cube.cube_intersection_mask (Cube.py:95-138): mask_out[n] (0/1), t_near_out[n] */
+int rt_unit_slab_mask(int device, const double *lo, const double *hi, int outside_hits_only, const double *origins,
+                      const double *directions, int64_t n, uint8_t *mask_out, double *t_near_out);
+
 #ifdef __cplusplus
 }
 #endif

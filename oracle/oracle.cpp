@@ -428,6 +428,8 @@ void initial_ray(const rt_scene_desc *s, int W, int H, int i, int j, V3 &o, V3 &
     d = dir / norm(dir);
 }
 
+/* pixel order of a rank's output (include/rt_amd.h, rt_tile_layout): row-major for world == 1, else the
+ * rank's tiles t = rank, rank+world, ... each as a full tw x th block (-1 = padding outside the image) */
 void tile_layout(const rt_render_params *p, std::vector<int64_t> &pix) {
     int W = p->width, H = p->height;
     int world = p->world > 1 ? p->world : 1, rank = p->world > 1 ? p->rank : 0;
@@ -439,10 +441,13 @@ void tile_layout(const rt_render_params *p, std::vector<int64_t> &pix) {
         return;
     }
     int tx = (W + tw - 1) / tw, ty = (H + th - 1) / th;
-    for (int t = rank; t < tx * ty; t += world) {
+    int per_rank = (tx * ty + world - 1) / world;
+    for (int j = 0; j < per_rank; ++j) {
+        int t = rank + j * world;
         int x0 = (t % tx) * tw, y0 = (t / tx) * th;
-        for (int y = y0; y < y0 + th && y < H; ++y)
-            for (int x = x0; x < x0 + tw && x < W; ++x) pix.push_back((int64_t)y * W + x);
+        for (int y = y0; y < y0 + th; ++y)
+            for (int x = x0; x < x0 + tw; ++x)
+                pix.push_back((t < tx * ty && y < H && x < W) ? (int64_t)y * W + x : -1);
     }
 }
 
@@ -500,6 +505,12 @@ int orc_render(const rt_scene_desc *s, const rt_render_params *p, double *rgb_f6
         Counters c;
 #pragma omp for schedule(dynamic, 64)
         for (int64_t k = 0; k < (int64_t)pix.size(); ++k) {
+            if (pix[k] < 0) {   /* tile padding: stays zero */
+                if (ids) ids[k] = 0;
+                if (rgb_f64) { rgb_f64[3 * k] = 0; rgb_f64[3 * k + 1] = 0; rgb_f64[3 * k + 2] = 0; }
+                if (rgb8) { rgb8[3 * k] = 0; rgb8[3 * k + 1] = 0; rgb8[3 * k + 2] = 0; }
+                continue;
+            }
             int i = (int)(pix[k] / p->width), j = (int)(pix[k] % p->width);
             V3 o, d;
             initial_ray(s, p->width, p->height, i, j, o, d);

@@ -1,0 +1,1252 @@
+// rt_amd.hip - HIP kernels (gfx950) and the C-ABI of include/rt_amd.h.
+//
+// Wavefront pipeline, one recursion level of the reference's ray_tracing()
+// (ray_tracer.py:36-133) per iteration, no host synchronisation inside a frame:
+//
+//   k_gen        camera rays, one lane per pixel, 8x8 pixel tile per wave     (ray_functions.py:7-43)
+//   per level:
+//     k_intersect  nearest hit of every queued ray, miss -> background, hit -> compacted hit list
+//                                                                              (BSPNode.py:123-210)
+//     k_shadow     one lane per (hit, shadow light, a, b) soft-shadow ray, generated in registers,
+//                  lit bits reduced per (hit, light) with ballot/popcount       (Light.py:178-288)
+//     k_shade      Phong terms, framebuffer accumulation, reflection / transparency rays appended to
+//                  the next level's queue with a wave-level prefix sum          (Light.py:35-175,
+//                                                                               ray_tracer.py:77-132)
+//   k_resolve    clip + float32 / uint8 quantisation                           (ray_tracer.py:30, util.py:98)
+//
+// The colour recursion  colour = through*T + (diff+spec)*(1-T) + refl*Kr  is linear in the child
+// colours, so each queued ray carries a throughput and adds throughput*local to its pixel.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rt_amd.h"
+#include "rt_device.hpp"
+
+#define RT_BLOCK 256
+#define RT_MAX_LEVELS 64
+#define RT_INVALID_SLOT 0xFFFFFFFFu
+
+// ------------------------------------------------------------------------------------------------
+// device-side frame state
+// ------------------------------------------------------------------------------------------------
+struct FrameCtl {
+    uint32_t n_rays[RT_MAX_LEVELS + 2];
+    uint32_t n_hits[RT_MAX_LEVELS + 2];
+    uint32_t overflow;
+    uint32_t pad;
+    unsigned long long reflect_rays, transmit_rays, primary_rays;
+};
+
+struct RayQ {            // SoA ray queue in HBM
+    double *ox, *oy, *oz, *dx, *dy, *dz;   // origin, direction (float64: they feed decisions)
+    double *tr, *tg, *tb;                  // throughput
+    uint32_t *slot;                        // output slot (RT_INVALID_SLOT = padding lane)
+    uint32_t *gpix;                        // global pixel index: jitter hash key
+    uint32_t *path;                        // path code: root 1, through 2k, reflect 2k+1
+};
+
+struct HitBuf {          // per ray slot of the CURRENT queue
+    double *px, *py, *pz;
+    int32_t *id;
+    uint32_t *list;      // compacted indices of rays that hit something
+    uint32_t *lit;       // [cap * n_shadow_lights] lit-sample counters
+};
+
+struct GenParams {
+    double pos[3], X[3], Y[3], p00[3];
+    double hg, wg;
+    int32_t W, H, tiles_x, n_tiles, rank, world, tw, th;
+    uint32_t n_slots;
+};
+
+struct LevelParams {
+    int32_t level, last_level;   // last_level: children are not traced, they return the background
+    int32_t sh_rays, jitter;
+    uint32_t seed, cap;
+    int32_t flags;
+};
+
+// XCD-aware chunk walk: workgroups b and b+8 share an XCD (and its L2), so XCD x = b % 8 walks one
+// contiguous eighth of the queue - rays that are neighbours in the queue (= in the image) keep
+// hitting the same L2.  A chunk is RT_BLOCK consecutive items.  Speed only, never correctness.
+struct ChunkWalk {
+    uint32_t per, pos, step, base, nchunks;
+    __device__ ChunkWalk(uint64_t n_items) {
+        nchunks = (uint32_t)((n_items + RT_BLOCK - 1) / RT_BLOCK);
+        per = (nchunks + 7u) >> 3;
+        uint32_t xcd = blockIdx.x & 7u;
+        base = xcd * per;
+        pos = blockIdx.x >> 3;
+        step = gridDim.x >> 3;
+    }
+    __device__ bool next(uint64_t &first_item) {
+        if (pos >= per) return false;
+        uint32_t c = base + pos;
+        pos += step;
+        if (c >= nchunks) return false;
+        first_item = (uint64_t)c * RT_BLOCK;
+        return true;
+    }
+};
+
+__device__ __forceinline__ void fb_add(double *fb, uint32_t slot, d3 c) {
+    atomicAdd(fb + 3ull * slot + 0, c.x);
+    atomicAdd(fb + 3ull * slot + 1, c.y);
+    atomicAdd(fb + 3ull * slot + 2, c.z);
+}
+
+// ------------------------------------------------------------------------------------------------
+// nearest hit (BSPNode.intersect_vectorize, BSPNode.py:123-210, for one ray)
+// ------------------------------------------------------------------------------------------------
+// Semantics: best = Background point (far clip) -> root planes in list order -> DFS, left child
+// first, over every node whose box passes the slab test -> leaf primitives in list order; a
+// candidate replaces the current best only when its Euclidean distance is STRICTLY smaller.
+// Pre-order layout + skip links make the left-first DFS a linear walk without a stack.
+__device__ __forceinline__ Hit nearest_hit(const DScene &S, d3 o, d3 d) {
+    Hit best;
+    if (S.far_clip) {
+        best.p = mk3(RT_MAX_RENDER_DISTANCE, RT_MAX_RENDER_DISTANCE, RT_MAX_RENDER_DISTANCE);
+        best.dist = norm3(best.p - o);
+        if (!(best.dist < dinf())) { best.p = mk3(dnan(), dnan(), dnan()); best.dist = dinf(); }
+    } else {
+        best.p = mk3(dnan(), dnan(), dnan());
+        best.dist = dinf();
+    }
+    best.id = 0;
+    for (int k = 0; k < S.n_planes; ++k) {      // wave-uniform loop: scalar loads
+        double t;
+        if (plane_exact(o, d, S.planes[k], t)) consider_t(best, o, d, t, S.planes[k].id);
+    }
+    d3 inv = mk3(d.x != 0 ? 1.0 / d.x : dinf(), d.y != 0 ? 1.0 / d.y : dinf(), d.z != 0 ? 1.0 / d.z : dinf());
+    double a = dot3(d, d);
+    int i = 0;
+    const int n = S.n_nodes;
+    while (i < n) {
+        const DNode *nd = S.nodes + i;
+        double tn;
+        if (!slab_exact(o, inv, nd->lo, nd->hi, false, tn)) {
+            i = nd->skip;
+            continue;
+        }
+        int first = nd->first;
+        if (first >= 0) {
+            int cnt = nd->count;
+            for (int e = 0; e < cnt; ++e) {
+                const DPrim *pr = S.prims + S.leaf_prim[first + e];
+                double t;
+                if (pr->kind == 1) {
+                    if (sphere_exact(o, d, a, pr->a, pr->b[0], t)) consider_t(best, o, d, t, pr->id);
+                } else {
+                    if (slab_exact(o, inv, pr->a, pr->b, true, t)) consider_t(best, o, d, t, pr->id);
+                }
+            }
+        }
+        i = i + 1;
+    }
+    return best;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(RT_BLOCK) k_gen(GenParams g, RayQ q, FrameCtl *ctl) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl->n_rays[0] = g.n_slots;
+    }
+    ChunkWalk walk(g.n_slots);
+    uint64_t first;
+    unsigned long long valid_total = 0;
+    while (walk.next(first)) {
+        uint64_t k = first + threadIdx.x;
+        if (k >= g.n_slots) continue;
+        uint32_t tile_local = (uint32_t)(k / (uint32_t)(g.tw * g.th));
+        uint32_t lane = (uint32_t)(k % (uint32_t)(g.tw * g.th));
+        uint32_t tile = g.world > 1 ? (uint32_t)g.rank + tile_local * (uint32_t)g.world : tile_local;
+        int x = (int)(tile % (uint32_t)g.tiles_x) * g.tw + (int)(lane % (uint32_t)g.tw);
+        int y = (int)(tile / (uint32_t)g.tiles_x) * g.th + (int)(lane / (uint32_t)g.tw);
+        bool valid = tile < (uint32_t)g.n_tiles && x < g.W && y < g.H;
+        if (!valid) {
+            q.slot[k] = RT_INVALID_SLOT;
+            continue;
+        }
+        // ray_functions.py:31-41
+        d3 pos = ld3(g.pos), X = ld3(g.X), Y = ld3(g.Y), p00 = ld3(g.p00);
+        d3 dest = (p00 - ((double)y * g.hg) * Y) + ((double)x * g.wg) * X;
+        d3 dir = dest - pos;
+        d3 dn = dir / norm3(dir);
+        q.ox[k] = pos.x; q.oy[k] = pos.y; q.oz[k] = pos.z;
+        q.dx[k] = dn.x; q.dy[k] = dn.y; q.dz[k] = dn.z;
+        q.tr[k] = 1.0; q.tg[k] = 1.0; q.tb[k] = 1.0;
+        uint32_t gp = (uint32_t)y * (uint32_t)g.W + (uint32_t)x;
+        q.slot[k] = g.world > 1 ? (uint32_t)k : gp;
+        q.gpix[k] = gp;
+        q.path[k] = 1u;
+        valid_total++;
+    }
+    // primary-ray count (padding lanes excluded)
+    for (int off = 32; off > 0; off >>= 1) valid_total += __shfl_down(valid_total, off);
+    if ((threadIdx.x & 63) == 0 && valid_total) atomicAdd(&ctl->primary_rays, valid_total);
+}
+
+// arbitrary ray batch (rt_trace / rt_intersect): AoS float64 -> queue
+__global__ void __launch_bounds__(RT_BLOCK) k_load_rays(const double *o, const double *d, uint32_t n, RayQ q,
+                                                        FrameCtl *ctl) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl->n_rays[0] = n;
+        ctl->primary_rays = n;
+    }
+    for (uint64_t k = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x; k < n; k += (uint64_t)gridDim.x * RT_BLOCK) {
+        q.ox[k] = o[3 * k]; q.oy[k] = o[3 * k + 1]; q.oz[k] = o[3 * k + 2];
+        q.dx[k] = d[3 * k]; q.dy[k] = d[3 * k + 1]; q.dz[k] = d[3 * k + 2];
+        q.tr[k] = 1.0; q.tg[k] = 1.0; q.tb[k] = 1.0;
+        q.slot[k] = (uint32_t)k;
+        q.gpix[k] = (uint32_t)k;
+        q.path[k] = 1u;
+    }
+}
+
+__global__ void __launch_bounds__(RT_BLOCK) k_intersect(DScene S, LevelParams lp, RayQ q, HitBuf hb, FrameCtl *ctl,
+                                                        double *fb, int32_t *ids_out) {
+    if (ctl->overflow) return;   // a queue overflowed earlier in this frame: the frame is void
+    const uint32_t n = min(ctl->n_rays[lp.level], lp.cap);
+    ChunkWalk walk(n);
+    uint64_t first;
+    const int lane = threadIdx.x & 63;
+    while (walk.next(first)) {
+        uint64_t k = first + threadIdx.x;
+        bool active = k < n;
+        uint32_t slot = active ? q.slot[k] : RT_INVALID_SLOT;
+        active = active && slot != RT_INVALID_SLOT;
+        bool has_hit = false;
+        if (active) {
+            d3 o = mk3(q.ox[k], q.oy[k], q.oz[k]);
+            d3 d = mk3(q.dx[k], q.dy[k], q.dz[k]);
+            Hit h = nearest_hit(S, o, d);
+            if (ids_out && lp.level == 0) ids_out[slot] = h.id;
+            if (h.id == 0) {
+                // ray_tracer.py:65,72,132: misses keep the background colour
+                d3 thr = mk3(q.tr[k], q.tg[k], q.tb[k]);
+                fb_add(fb, slot, thr * ld3(S.bg));
+            } else {
+                hb.px[k] = h.p.x; hb.py[k] = h.p.y; hb.pz[k] = h.p.z;
+                hb.id[k] = h.id;
+                has_hit = true;
+            }
+        }
+        // wave-level compaction of the hit list: one atomic per wave
+        unsigned long long mask = __ballot(has_hit);
+        if (mask) {
+            int leader = __ffsll((long long)mask) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&ctl->n_hits[lp.level], (uint32_t)__popcll(mask));
+            base = __shfl(base, leader);
+            if (has_hit) hb.list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)k;
+        }
+    }
+}
+
+// one lane per soft-shadow ray (Light.compute_shadows / get_shadow_rays, Light.py:178-288)
+__global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene S, LevelParams lp, RayQ q, HitBuf hb, FrameCtl *ctl) {
+    if (ctl->overflow) return;
+    const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
+    const uint32_t s = (uint32_t)lp.sh_rays, s2 = s * s;
+    const uint32_t nsl = (uint32_t)S.n_shadow_lights;
+    const uint64_t total = (uint64_t)n_hits * nsl * s2;
+    ChunkWalk walk(total);
+    uint64_t first;
+    const int lane = threadIdx.x & 63;
+    while (walk.next(first)) {
+        uint64_t g = first + threadIdx.x;
+        bool active = g < total;
+        bool lit = false;
+        uint64_t seg = active ? g / s2 : ~0ull;       // (hit, light) pair: h * nsl + ml
+        if (active) {
+            uint32_t h = (uint32_t)(seg / nsl), ml = (uint32_t)(seg % nsl), kk = (uint32_t)(g % s2);
+            uint32_t a = kk / s, b = kk % s;
+            uint32_t r = hb.list[h];
+            int m = S.shadow_lights[ml];
+            d3 P = mk3(hb.px[r], hb.py[r], hb.pz[r]);
+            const DLight &Lt = S.lights[m];
+            d3 lpos = ld3(Lt.pos);
+            d3 dl = lpos - P;                              // Light.py:48-50
+            d3 L = dl / norm3(dl);
+            d3 up, right;
+            light_basis(neg3(L), up, right);               // Light.py:257
+            double radius = Lt.radius;
+            double gsz = radius / (double)(int)s;          // Light.py:254
+            double c0 = (radius - gsz) / 2;
+            d3 p00 = (lpos + c0 * up) - c0 * right;        // Light.py:260
+            d3 src = (p00 - ((double)b * gsz) * up) + ((double)a * gsz) * right;   // Light.py:273-274
+            d3 u1 = mk3(0, 0, 0), u2 = mk3(0, 0, 0);
+            if (lp.jitter) {
+                u1 = jitter3(lp.seed, q.gpix[r], q.path[r], (uint32_t)m, kk, 0u, gsz);
+                u2 = jitter3(lp.seed, q.gpix[r], q.path[r], (uint32_t)m, kk, 1u, gsz);
+            }
+            src = src + (u1 * up + u2 * right);            // Light.py:277-279
+            d3 vec = P - src;
+            d3 dir = vec / (norm3(vec) + RT_EPSILON);      // Light.py:283-286
+            Hit x = nearest_hit(S, src, dir);
+            lit = norm3(x.p - P) < RT_EPSILON;             // Light.py:219-221 (NaN -> unlit)
+        }
+        // segmented popcount: consecutive lanes of one (hit, light) pair share a counter
+        unsigned long long litmask = __ballot(lit);
+        uint64_t prev = __shfl_up(seg, 1);
+        bool leader = active && (lane == 0 || prev != seg);
+        unsigned long long leaders = __ballot(leader);
+        if (leader) {
+            unsigned long long above = (lane == 63) ? 0ull : (leaders >> (lane + 1));
+            int next = above ? (lane + 1 + (__ffsll((long long)above) - 1)) : 64;
+            unsigned long long segmask = (next == 64 ? ~0ull : ((1ull << next) - 1ull)) & ~((1ull << lane) - 1ull);
+            uint32_t cnt = (uint32_t)__popcll(litmask & segmask);
+            if (cnt) atomicAdd(&hb.lit[seg], cnt);
+        }
+    }
+}
+
+// Phong shading + secondary-ray generation for every hit of the level
+__global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, LevelParams lp, RayQ q, RayQ qn, HitBuf hb, FrameCtl *ctl,
+                                                    double *fb) {
+    if (ctl->overflow) return;
+    const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
+    const uint32_t nsl = (uint32_t)S.n_shadow_lights;
+    const double s2 = (double)(lp.sh_rays * lp.sh_rays);
+    ChunkWalk walk(n_hits);
+    uint64_t first;
+    const int lane = threadIdx.x & 63;
+    unsigned long long n_refl = 0, n_trans = 0;
+    while (walk.next(first)) {
+        uint64_t h = first + threadIdx.x;
+        bool active = h < n_hits;
+        int n_child = 0;
+        d3 o_t, d_t, thr_t, o_r, d_r, thr_r;
+        bool want_t = false, want_r = false;
+        uint32_t slot = 0, gpix = 0, path = 0;
+        if (active) {
+            uint32_t r = hb.list[h];
+            d3 d = mk3(q.dx[r], q.dy[r], q.dz[r]);
+            d3 thr = mk3(q.tr[r], q.tg[r], q.tb[r]);
+            d3 P = mk3(hb.px[r], hb.py[r], hb.pz[r]);
+            slot = q.slot[r]; gpix = q.gpix[r]; path = q.path[r];
+            int32_t id = hb.id[r], mi;
+            d3 N = surface_normal(S, id, P, mi);                         // ray_tracer.py:77-78
+            d3 Kd = mk3(0, 0, 0), Ks = mk3(0, 0, 0), Kr = mk3(0, 0, 0);
+            double T = 0;
+            int32_t phong = 0, mflags = 0;
+            if (mi >= 0 && mi < S.n_mats) {                              // Material.py:23-62
+                const DMat &M = S.mats[mi];
+                Kd = ld3(M.kd); Ks = ld3(M.ks); Kr = ld3(M.kr);
+                T = M.T; phong = M.phong; mflags = M.flags;
+            }
+            d3 V = neg3(d);
+            d3 Nh = N / norm3(N);                                        // ray_functions.py:98-99
+            d3 diff = mk3(0, 0, 0), spec = mk3(0, 0, 0);
+            uint32_t ml = 0;
+            for (int m = 0; m < S.n_lights; ++m) {
+                const DLight &Lt = S.lights[m];
+                d3 dl = ld3(Lt.pos) - P;                                 // Light.py:35-53
+                d3 L = dl / norm3(dl);
+                double I = 1.0;                                          // Light.py:199-200
+                if (Lt.shadow != 0) {
+                    uint64_t seg = (uint64_t)h * nsl + ml;
+                    uint32_t cnt = hb.lit[seg];
+                    hb.lit[seg] = 0;                                     // ready for the next level
+                    ml++;
+                    double frac = (double)cnt / s2;                  // Light.py:223
+                    I = (1.0 - Lt.shadow) + Lt.shadow * frac;            // Light.py:226
+                }
+                I = I < 0 ? 0 : (I > 1 ? 1 : I);                         // Light.py:84
+                d3 col = ld3(Lt.color);
+                d3 Ims = (Lt.spec * I) * col;                            // Light.py:87
+                d3 Imd = I * col;                                        // Light.py:91
+                double ldn = dot3(L, N);                                 // Light.py:123-125
+                ldn = isnan(ldn) ? ldn : (ldn > 0 ? ldn : 0);
+                d3 dterm = (ldn * Kd) * Imd;
+                diff = (m == 0) ? dterm : diff + dterm;
+                double dp = dot3(L, Nh);                                 // ray_functions.py:101-103
+                d3 R = (2 * dp) * Nh - L;
+                double rv = dot3(R, V);                                  // Light.py:169
+                double pw = ipow(rv, phong);
+                d3 sterm = (pw * Ks) * Ims;                              // Light.py:171
+                spec = (m == 0) ? sterm : spec + sterm;
+            }
+            spec = mk3(nan_to_num(spec.x), nan_to_num(spec.y), nan_to_num(spec.z));   // Light.py:173
+            double nt = 1.0 - T;
+            d3 base = (diff + spec) * mk3(nt, nt, nt);                   // ray_tracer.py:105-106
+            fb_add(fb, slot, thr * base);
+            if (mflags & 1) {                                            // ray_tracer.py:108-116
+                thr_t = thr * mk3(T, T, T);
+                if (lp.last_level) fb_add(fb, slot, thr_t * ld3(S.bg));  // child returns background (:62-63)
+                else {
+                    want_t = true;
+                    d_t = d;
+                    o_t = P + RT_EPSILON * d;
+                }
+            }
+            if (mflags & 2) {                                            // ray_tracer.py:119-129
+                thr_r = thr * Kr;
+                if (lp.last_level) fb_add(fb, slot, thr_r * ld3(S.bg));
+                else {
+                    want_r = true;
+                    double dp = dot3(V, Nh);
+                    d_r = (2 * dp) * Nh - V;                             // ray_functions.py:103
+                    o_r = P + RT_EPSILON * d_r;
+                }
+            }
+            n_child = (want_t ? 1 : 0) + (want_r ? 1 : 0);
+        }
+        // wave-level exclusive prefix sum of n_child -> one atomic per wave on the next queue's tail
+        int incl = n_child;
+        for (int off = 1; off < 64; off <<= 1) {
+            int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        int total = __shfl(incl, 63);
+        if (total) {
+            uint32_t base = 0;
+            if (lane == 63) base = atomicAdd(&ctl->n_rays[lp.level + 1], (uint32_t)total);
+            base = __shfl(base, 63);
+            uint32_t w = base + (uint32_t)(incl - n_child);
+            if (base + (uint32_t)total > lp.cap) {
+                if (lane == 63) ctl->overflow = 1;     // frame is invalid; host re-renders with larger queues
+            } else {
+                if (want_t) {
+                    qn.ox[w] = o_t.x; qn.oy[w] = o_t.y; qn.oz[w] = o_t.z;
+                    qn.dx[w] = d_t.x; qn.dy[w] = d_t.y; qn.dz[w] = d_t.z;
+                    qn.tr[w] = thr_t.x; qn.tg[w] = thr_t.y; qn.tb[w] = thr_t.z;
+                    qn.slot[w] = slot; qn.gpix[w] = gpix; qn.path[w] = path * 2u;
+                    w++;
+                    n_trans++;
+                }
+                if (want_r) {
+                    qn.ox[w] = o_r.x; qn.oy[w] = o_r.y; qn.oz[w] = o_r.z;
+                    qn.dx[w] = d_r.x; qn.dy[w] = d_r.y; qn.dz[w] = d_r.z;
+                    qn.tr[w] = thr_r.x; qn.tg[w] = thr_r.y; qn.tb[w] = thr_r.z;
+                    qn.slot[w] = slot; qn.gpix[w] = gpix; qn.path[w] = path * 2u + 1u;
+                    n_refl++;
+                }
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        n_refl += __shfl_down(n_refl, off);
+        n_trans += __shfl_down(n_trans, off);
+    }
+    if (lane == 0) {
+        if (n_refl) atomicAdd(&ctl->reflect_rays, n_refl);
+        if (n_trans) atomicAdd(&ctl->transmit_rays, n_trans);
+    }
+}
+
+// clip(0,1) (ray_tracer.py:30) and save_image's truncating quantisation (util.py:98)
+__global__ void __launch_bounds__(RT_BLOCK) k_resolve(const double *fb, uint64_t n_values, float *rgb, uint8_t *rgb8) {
+    for (uint64_t k = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x; k < n_values; k += (uint64_t)gridDim.x * RT_BLOCK) {
+        double v = fb[k];
+        double c = v < 0 ? 0 : (v > 1 ? 1 : v);
+        if (rgb) rgb[k] = (float)c;
+        if (rgb8) rgb8[k] = isnan(c) ? (uint8_t)0 : (uint8_t)(c * 255);
+    }
+}
+
+__global__ void __launch_bounds__(RT_BLOCK) k_intersect_only(DScene S, const double *o, const double *d, uint64_t n,
+                                                             double *pts, int64_t *ids) {
+    for (uint64_t k = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x; k < n; k += (uint64_t)gridDim.x * RT_BLOCK) {
+        Hit h = nearest_hit(S, ld3(o + 3 * k), ld3(d + 3 * k));
+        pts[3 * k] = h.p.x; pts[3 * k + 1] = h.p.y; pts[3 * k + 2] = h.p.z;
+        ids[k] = h.id;
+    }
+}
+
+__global__ void k_deinterleave_u8(const uint8_t *packed, int64_t stride, uint8_t *image, int W, int H, int tw, int th,
+                                  int tiles_x, int n_tiles, int world, int tiles_per_rank) {
+    uint64_t total = (uint64_t)world * tiles_per_rank * tw * th;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t per_rank = (uint32_t)tiles_per_rank * tw * th;
+        uint32_t r = (uint32_t)(k / per_rank), loc = (uint32_t)(k % per_rank);
+        uint32_t tile = r + (loc / (uint32_t)(tw * th)) * (uint32_t)world, lane = loc % (uint32_t)(tw * th);
+        int x = (int)(tile % (uint32_t)tiles_x) * tw + (int)(lane % (uint32_t)tw);
+        int y = (int)(tile / (uint32_t)tiles_x) * th + (int)(lane / (uint32_t)tw);
+        if (tile >= (uint32_t)n_tiles || x >= W || y >= H) continue;
+        const uint8_t *src = packed + (uint64_t)r * stride + 3ull * loc;
+        uint8_t *dst = image + 3ull * ((uint64_t)y * W + x);
+        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+    }
+}
+
+// ---- unit kernels (kernel-level parity tests; same device functions as the frame path) --------
+__global__ void k_unit_prim(int kind, const double *par, const double *o, const double *d, uint64_t n, double *out) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        d3 oo = ld3(o + 3 * k), dd = ld3(d + 3 * k);
+        d3 inv = mk3(dd.x != 0 ? 1.0 / dd.x : dinf(), dd.y != 0 ? 1.0 / dd.y : dinf(), dd.z != 0 ? 1.0 / dd.z : dinf());
+        double t = 0;
+        bool ok = false;
+        if (kind == RT_SURF_SPHERE) ok = sphere_exact(oo, dd, dot3(dd, dd), par, par[3], t);
+        else if (kind == RT_SURF_BOX) ok = slab_exact(oo, inv, par, par + 3, true, t);
+        else if (kind == RT_SURF_PLANE) {
+            DPlane pl;
+            pl.n[0] = par[0]; pl.n[1] = par[1]; pl.n[2] = par[2]; pl.d = par[3];
+            ok = plane_exact(oo, dd, pl, t);
+        }
+        d3 p = ok ? oo + t * dd : mk3(dnan(), dnan(), dnan());
+        out[3 * k] = p.x; out[3 * k + 1] = p.y; out[3 * k + 2] = p.z;
+    }
+}
+__global__ void k_unit_normals(int kind, const double *par, const double *pts, uint64_t n, double *out) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        d3 P = ld3(pts + 3 * k), N = mk3(0, 0, 0);
+        if (kind == RT_SURF_SPHERE) {
+            d3 dir = P - ld3(par);
+            N = dir / norm3(dir);
+        } else if (kind == RT_SURF_BOX) N = box_normal(P, ld3(par + 6), par[9]);
+        else if (kind == RT_SURF_PLANE) N = ld3(par);
+        out[3 * k] = N.x; out[3 * k + 1] = N.y; out[3 * k + 2] = N.z;
+    }
+}
+__global__ void k_unit_slab(const double *lo, const double *hi, int outside_only, const double *o, const double *d,
+                            uint64_t n, uint8_t *mask, double *tn) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        d3 oo = ld3(o + 3 * k), dd = ld3(d + 3 * k);
+        d3 inv = mk3(dd.x != 0 ? 1.0 / dd.x : dinf(), dd.y != 0 ? 1.0 / dd.y : dinf(), dd.z != 0 ? 1.0 / dd.z : dinf());
+        double t;
+        mask[k] = slab_exact(oo, inv, lo, hi, outside_only != 0, t) ? 1 : 0;
+        tn[k] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_create_error;
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+    std::vector<void *> scene_allocs;
+    DScene S{};
+    rt_scene_desc host{};   // scalar fields only (camera, settings)
+    // frame buffers
+    uint64_t cap = 0;       // ray-queue capacity
+    uint64_t fb_slots = 0;
+    double growth = 2.0;    // queue capacity = growth * primary slots
+    std::vector<void *> frame_allocs;
+    RayQ q[2]{};
+    HitBuf hb{};
+    double *fb = nullptr;
+    FrameCtl *ctl = nullptr;
+    FrameCtl *h_ctl = nullptr;   // pinned
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool frame_pending = false;
+    rt_render_params last{};
+    int32_t last_sh = 0, last_rec = 0;
+    uint64_t last_slots = 0;
+    int grid = 2048;
+};
+
+static int fail(rt_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->error = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                                   \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) {                                                                              \
+            int code_ = (e_ == hipErrorOutOfMemory) ? RT_ERR_OOM : RT_ERR_HIP;                               \
+            return fail(ctx, code_, std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+        }                                                                                                    \
+    } while (0)
+
+template <typename T>
+static int upload(rt_ctx *ctx, std::vector<void *> &owner, const std::vector<T> &h, const T **out) {
+    void *p = nullptr;
+    size_t bytes = (h.size() ? h.size() : 1) * sizeof(T);
+    HIP_TRY(ctx, hipMalloc(&p, bytes));
+    owner.push_back(p);
+    if (!h.empty()) HIP_TRY(ctx, hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T *)p;
+    return RT_OK;
+}
+
+static float round_down(double v) {
+    float f = (float)v;
+    if ((double)f > v) f = nextafterf(f, -INFINITY);
+    return f;
+}
+static float round_up(double v) {
+    float f = (float)v;
+    if ((double)f < v) f = nextafterf(f, INFINITY);
+    return f;
+}
+
+static int check_scene(const rt_scene_desc *s, std::string &why) {
+#define NEED(cond, text) if (!(cond)) { why = text; return RT_ERR_INVALID_ARG; }
+    NEED(s, "scene is NULL");
+    NEED(s->abi_version == RT_AMD_ABI_VERSION, "rt_scene_desc.abi_version mismatch");
+    NEED(s->n_surfaces >= 0 && s->n_spheres >= 0 && s->n_boxes >= 0 && s->n_planes >= 0 && s->n_materials >= 0 &&
+         s->n_lights >= 0 && s->n_nodes >= 1 && s->n_leaf_refs >= 0, "negative count (or no BSP node)");
+    NEED(s->n_surfaces == 0 || (s->surf_kind && s->surf_geom && s->surf_mat), "surface table pointer is NULL");
+    NEED(s->n_spheres == 0 || (s->sph_center && s->sph_radius && s->sph_r2 && s->sph_id), "sphere table pointer is NULL");
+    NEED(s->n_boxes == 0 || (s->box_center && s->box_scale && s->box_lo && s->box_hi && s->box_id), "box table pointer is NULL");
+    NEED(s->n_planes == 0 || (s->pln_normal && s->pln_d && s->pln_id), "plane table pointer is NULL");
+    NEED(s->n_materials == 0 || (s->mat_kd && s->mat_ks && s->mat_kr && s->mat_phong && s->mat_transparency), "material table pointer is NULL");
+    NEED(s->n_lights == 0 || (s->lgt_pos && s->lgt_color && s->lgt_spec && s->lgt_shadow && s->lgt_radius), "light table pointer is NULL");
+    NEED(s->node_lo && s->node_hi && s->node_right && s->node_first && s->node_count, "node table pointer is NULL");
+    NEED(s->n_leaf_refs == 0 || s->leaf_prim, "leaf_prim is NULL");
+    const int np = s->n_spheres + s->n_boxes;
+    for (int i = 0; i < s->n_leaf_refs; ++i) NEED(s->leaf_prim[i] >= 0 && s->leaf_prim[i] < np, "leaf_prim entry out of range");
+    for (int i = 0; i < s->n_nodes; ++i) {
+        if (s->node_right[i] >= 0) {
+            NEED(s->node_right[i] > i + 1 && s->node_right[i] < s->n_nodes && i + 1 < s->n_nodes, "node_right out of range / not pre-order");
+        } else {
+            NEED(s->node_first[i] >= 0 && s->node_count[i] >= 0 && s->node_first[i] + s->node_count[i] <= s->n_leaf_refs, "leaf range out of bounds");
+        }
+    }
+    for (int i = 0; i < s->n_surfaces; ++i) {
+        int k = s->surf_kind[i], g = s->surf_geom[i];
+        int lim = k == RT_SURF_SPHERE ? s->n_spheres : k == RT_SURF_BOX ? s->n_boxes : k == RT_SURF_PLANE ? s->n_planes : 0;
+        NEED(k >= 0 && k <= 3, "surf_kind out of range");
+        NEED(k == RT_SURF_BACKGROUND || (g >= 0 && g < lim), "surf_geom out of range");
+    }
+#undef NEED
+    return RT_OK;
+}
+
+extern "C" int rt_abi_version(void) { return RT_AMD_ABI_VERSION; }
+
+extern "C" const char *rt_last_error(const rt_ctx *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
+    if (!out) return fail(nullptr, RT_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    std::string why;
+    if (int rc = check_scene(s, why)) return fail(nullptr, rc, why);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(nullptr, RT_ERR_NO_DEVICE, "device ordinal out of range");
+    rt_ctx *ctx = new rt_ctx();
+    ctx->device = device;
+    auto bail = [&](int rc) {
+        g_create_error = ctx->error;
+        rt_destroy(ctx);
+        return rc;
+    };
+#define TRY_C(expr) do { int rc_ = (expr); if (rc_ != RT_OK) return bail(rc_); } while (0)
+#define HIP_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ctx->error = std::string(#expr) + ": " + hipGetErrorString(e_); return bail(e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP); } } while (0)
+    HIP_C(hipSetDevice(device));
+    HIP_C(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIP_C(hipEventCreate(&ctx->ev0));
+    HIP_C(hipEventCreate(&ctx->ev1));
+    HIP_C(hipMalloc((void **)&ctx->ctl, sizeof(FrameCtl)));
+    HIP_C(hipHostMalloc((void **)&ctx->h_ctl, sizeof(FrameCtl), hipHostMallocDefault));
+    hipDeviceProp_t prop;
+    HIP_C(hipGetDeviceProperties(&prop, device));
+    ctx->grid = prop.multiProcessorCount * 8;
+    ctx->grid = (ctx->grid + 7) & ~7;
+
+    // ---- primitives: spheres first, then boxes ----
+    const int ns = s->n_spheres, nb = s->n_boxes;
+    std::vector<DPrim> prims((size_t)ns + nb);
+    std::vector<FPrim> fprims((size_t)ns + nb);
+    for (int i = 0; i < ns; ++i) {
+        DPrim &p = prims[i];
+        memset(&p, 0, sizeof(p));
+        for (int k = 0; k < 3; ++k) p.a[k] = s->sph_center[3 * i + k];
+        p.b[0] = s->sph_r2[i]; p.b[1] = s->sph_radius[i]; p.b[2] = 0;
+        p.kind = 1; p.id = s->sph_id[i];
+        FPrim &f = fprims[i];
+        memset(&f, 0, sizeof(f));
+        for (int k = 0; k < 3; ++k) f.a[k] = (float)p.a[k];
+        f.r = round_up(fabs(s->sph_radius[i]));
+        f.kind = 1;
+    }
+    for (int i = 0; i < nb; ++i) {
+        DPrim &p = prims[(size_t)ns + i];
+        memset(&p, 0, sizeof(p));
+        for (int k = 0; k < 3; ++k) { p.a[k] = s->box_lo[3 * i + k]; p.b[k] = s->box_hi[3 * i + k]; }
+        p.kind = 2; p.id = s->box_id[i];
+        FPrim &f = fprims[(size_t)ns + i];
+        memset(&f, 0, sizeof(f));
+        for (int k = 0; k < 3; ++k) { f.a[k] = round_down(p.a[k]); f.b[k] = round_up(p.b[k]); }
+        f.kind = 2;
+    }
+    TRY_C(upload(ctx, ctx->scene_allocs, prims, &ctx->S.prims));
+    TRY_C(upload(ctx, ctx->scene_allocs, fprims, &ctx->S.fprims));
+
+    // ---- nodes, with skip links ----
+    const int nn = s->n_nodes;
+    std::vector<DNode> nodes(nn);
+    std::vector<FNode> fnodes(nn);
+    std::vector<int32_t> skip(nn, 0);
+    {
+        // subtree end of node i in pre-order: leaf -> i+1, internal -> end(right child); right children
+        // come later in the array, so a reverse sweep resolves them first
+        for (int i = nn - 1; i >= 0; --i) skip[i] = s->node_right[i] < 0 ? i + 1 : skip[s->node_right[i]];
+    }
+    for (int i = 0; i < nn; ++i) {
+        DNode &n = nodes[i];
+        for (int k = 0; k < 3; ++k) { n.lo[k] = s->node_lo[3 * i + k]; n.hi[k] = s->node_hi[3 * i + k]; }
+        n.skip = skip[i];
+        bool leaf = s->node_right[i] < 0;
+        n.first = leaf ? s->node_first[i] : -1;
+        n.count = leaf ? s->node_count[i] : 0;
+        n.pad = 0;
+        FNode &f = fnodes[i];
+        for (int k = 0; k < 3; ++k) { f.lo[k] = round_down(n.lo[k]); f.hi[k] = round_up(n.hi[k]); }
+        f.skip = skip[i];
+        f.first_count = !leaf ? -1 : ((n.first < (1 << 22) && n.count < 256) ? ((n.first << 8) | n.count) : -2);
+    }
+    TRY_C(upload(ctx, ctx->scene_allocs, nodes, &ctx->S.nodes));
+    TRY_C(upload(ctx, ctx->scene_allocs, fnodes, &ctx->S.fnodes));
+    std::vector<int32_t> leaf(s->leaf_prim, s->leaf_prim + s->n_leaf_refs);
+    TRY_C(upload(ctx, ctx->scene_allocs, leaf, &ctx->S.leaf_prim));
+
+    // ---- planes / surfaces / materials / lights ----
+    std::vector<DPlane> planes(s->n_planes);
+    for (int i = 0; i < s->n_planes; ++i) {
+        for (int k = 0; k < 3; ++k) planes[i].n[k] = s->pln_normal[3 * i + k];
+        planes[i].d = s->pln_d[i]; planes[i].id = s->pln_id[i]; planes[i].pad = 0;
+    }
+    TRY_C(upload(ctx, ctx->scene_allocs, planes, &ctx->S.planes));
+    std::vector<DSurf> surfs(s->n_surfaces);
+    for (int i = 0; i < s->n_surfaces; ++i) {
+        DSurf &d = surfs[i];
+        memset(&d, 0, sizeof(d));
+        d.kind = s->surf_kind[i]; d.mat = s->surf_mat[i];
+        int g = s->surf_geom[i];
+        if (d.kind == RT_SURF_SPHERE) for (int k = 0; k < 3; ++k) d.p[k] = s->sph_center[3 * g + k];
+        if (d.kind == RT_SURF_BOX) { for (int k = 0; k < 3; ++k) d.p[k] = s->box_center[3 * g + k]; d.p[3] = s->box_scale[g]; }
+        if (d.kind == RT_SURF_PLANE) for (int k = 0; k < 3; ++k) d.p[k] = s->pln_normal[3 * g + k];
+    }
+    TRY_C(upload(ctx, ctx->scene_allocs, surfs, &ctx->S.surfs));
+    std::vector<DMat> mats(s->n_materials);
+    for (int i = 0; i < s->n_materials; ++i) {
+        DMat &m = mats[i];
+        for (int k = 0; k < 3; ++k) { m.kd[k] = s->mat_kd[3 * i + k]; m.ks[k] = s->mat_ks[3 * i + k]; m.kr[k] = s->mat_kr[3 * i + k]; }
+        m.T = s->mat_transparency[i];
+        m.phong = s->mat_phong[i];
+        // ray_tracer.py:108 (any(T != 0)) and :119 (norm(Kr) != 0, evaluated like np.linalg.norm)
+        double nk = sqrt((m.kr[0] * m.kr[0] + m.kr[1] * m.kr[1]) + m.kr[2] * m.kr[2]);
+        m.flags = (m.T != 0 ? 1 : 0) | (nk != 0 ? 2 : 0);
+    }
+    TRY_C(upload(ctx, ctx->scene_allocs, mats, &ctx->S.mats));
+    std::vector<DLight> lights(s->n_lights);
+    std::vector<int32_t> sl;
+    for (int i = 0; i < s->n_lights; ++i) {
+        DLight &l = lights[i];
+        for (int k = 0; k < 3; ++k) { l.pos[k] = s->lgt_pos[3 * i + k]; l.color[k] = s->lgt_color[3 * i + k]; }
+        l.spec = s->lgt_spec[i]; l.shadow = s->lgt_shadow[i]; l.radius = s->lgt_radius[i];
+        if (l.shadow != 0) sl.push_back(i);   // Light.py:199: shadow_intensity == 0 casts no rays
+    }
+    TRY_C(upload(ctx, ctx->scene_allocs, lights, &ctx->S.lights));
+    TRY_C(upload(ctx, ctx->scene_allocs, sl, &ctx->S.shadow_lights));
+    ctx->S.n_prims = ns + nb; ctx->S.n_nodes = nn; ctx->S.n_planes = s->n_planes; ctx->S.n_surfs = s->n_surfaces;
+    ctx->S.n_mats = s->n_materials; ctx->S.n_lights = s->n_lights; ctx->S.n_shadow_lights = (int)sl.size();
+    ctx->S.far_clip = s->far_clip;
+    for (int k = 0; k < 3; ++k) ctx->S.bg[k] = s->background[k];
+    ctx->host = *s;   // pointers inside are NOT used after this call; scalars (camera, settings) are
+#undef TRY_C
+#undef HIP_C
+    *out = ctx;
+    return RT_OK;
+}
+
+static void free_frame(rt_ctx *ctx) {
+    for (void *p : ctx->frame_allocs) (void)hipFree(p);
+    ctx->frame_allocs.clear();
+    ctx->cap = 0;
+    ctx->fb_slots = 0;
+    ctx->fb = nullptr;
+}
+
+extern "C" int rt_destroy(rt_ctx *ctx) {
+    if (!ctx) return RT_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_frame(ctx);
+    for (void *p : ctx->scene_allocs) (void)hipFree(p);
+    if (ctx->ctl) (void)hipFree(ctx->ctl);
+    if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RT_OK;
+}
+
+template <typename T>
+static int dalloc(rt_ctx *ctx, T **p, uint64_t n) {
+    void *v = nullptr;
+    HIP_TRY(ctx, hipMalloc(&v, (n ? n : 1) * sizeof(T)));
+    ctx->frame_allocs.push_back(v);
+    *p = (T *)v;
+    return RT_OK;
+}
+
+// (re)allocate queues for `slots` primary slots; only grows
+static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
+    uint64_t want_cap = (uint64_t)((double)slots * ctx->growth) + 1024;
+    if (want_cap > 0xFFFFFFF0ull) return fail(ctx, RT_ERR_UNSUPPORTED, "ray queue would exceed 2^32 entries");
+    if (ctx->cap >= want_cap && ctx->fb_slots >= slots) return RT_OK;
+    HIP_TRY(ctx, hipDeviceSynchronize());   // rare: buffers of an in-flight frame are about to be replaced
+    free_frame(ctx);
+    uint64_t cap = want_cap;
+#define TRY_A(expr) do { int rc_ = (expr); if (rc_ != RT_OK) { free_frame(ctx); return rc_; } } while (0)
+    for (int i = 0; i < 2; ++i) {
+        RayQ &q = ctx->q[i];
+        TRY_A(dalloc(ctx, &q.ox, cap)); TRY_A(dalloc(ctx, &q.oy, cap)); TRY_A(dalloc(ctx, &q.oz, cap));
+        TRY_A(dalloc(ctx, &q.dx, cap)); TRY_A(dalloc(ctx, &q.dy, cap)); TRY_A(dalloc(ctx, &q.dz, cap));
+        TRY_A(dalloc(ctx, &q.tr, cap)); TRY_A(dalloc(ctx, &q.tg, cap)); TRY_A(dalloc(ctx, &q.tb, cap));
+        TRY_A(dalloc(ctx, &q.slot, cap)); TRY_A(dalloc(ctx, &q.gpix, cap)); TRY_A(dalloc(ctx, &q.path, cap));
+    }
+    HitBuf &hb = ctx->hb;
+    TRY_A(dalloc(ctx, &hb.px, cap)); TRY_A(dalloc(ctx, &hb.py, cap)); TRY_A(dalloc(ctx, &hb.pz, cap));
+    TRY_A(dalloc(ctx, &hb.id, cap)); TRY_A(dalloc(ctx, &hb.list, cap));
+    uint64_t nlit = cap * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1);
+    TRY_A(dalloc(ctx, &hb.lit, nlit));
+    HIP_TRY(ctx, hipMemsetAsync(hb.lit, 0, nlit * sizeof(uint32_t), ctx->stream));
+    TRY_A(dalloc(ctx, &ctx->fb, slots * 3));
+#undef TRY_A
+    ctx->cap = cap;
+    ctx->fb_slots = slots;
+    return RT_OK;
+}
+
+struct TileGeom {
+    int W, H, tw, th, tiles_x, tiles_y, n_tiles, world, rank, tiles_per_rank;
+    uint64_t slots;      // ray slots processed by this rank (tile padded)
+    uint64_t out_slots;  // entries in this rank's output buffers
+};
+
+static int tile_geom(const rt_render_params *p, TileGeom &g, std::string &why) {
+    if (!p) { why = "params is NULL"; return RT_ERR_INVALID_ARG; }
+    if (p->width <= 0 || p->height <= 0) { why = "width/height must be positive"; return RT_ERR_INVALID_ARG; }
+    g.W = p->width; g.H = p->height;
+    g.tw = p->tile_w > 0 ? p->tile_w : 8;
+    g.th = p->tile_h > 0 ? p->tile_h : 8;
+    g.world = p->world > 1 ? p->world : 1;
+    g.rank = g.world > 1 ? p->rank : 0;
+    if (g.rank < 0 || g.rank >= g.world) { why = "rank out of range"; return RT_ERR_INVALID_ARG; }
+    g.tiles_x = (g.W + g.tw - 1) / g.tw;
+    g.tiles_y = (g.H + g.th - 1) / g.th;
+    g.n_tiles = g.tiles_x * g.tiles_y;
+    g.tiles_per_rank = (g.n_tiles + g.world - 1) / g.world;
+    g.slots = (uint64_t)g.tiles_per_rank * g.tw * g.th;
+    g.out_slots = g.world > 1 ? g.slots : (uint64_t)g.W * g.H;
+    if ((uint64_t)g.W * g.H > 0xFFFFFFF0ull) { why = "image too large"; return RT_ERR_UNSUPPORTED; }
+    return RT_OK;
+}
+
+extern "C" int64_t rt_tile_pixels(const rt_render_params *p) {
+    TileGeom g;
+    std::string why;
+    if (tile_geom(p, g, why) != RT_OK) return -1;
+    return (int64_t)g.out_slots;
+}
+
+extern "C" int rt_tile_layout(const rt_render_params *p, int64_t *pixel_index) {
+    TileGeom g;
+    std::string why;
+    if (int rc = tile_geom(p, g, why)) return fail(nullptr, rc, why);
+    if (!pixel_index) return fail(nullptr, RT_ERR_INVALID_ARG, "pixel_index is NULL");
+    if (g.world == 1) {
+        for (int64_t k = 0; k < (int64_t)g.out_slots; ++k) pixel_index[k] = k;
+        return RT_OK;
+    }
+    for (uint64_t k = 0; k < g.slots; ++k) {
+        uint32_t tile = (uint32_t)g.rank + (uint32_t)(k / (uint32_t)(g.tw * g.th)) * (uint32_t)g.world;
+        uint32_t lane = (uint32_t)(k % (uint32_t)(g.tw * g.th));
+        int x = (int)(tile % (uint32_t)g.tiles_x) * g.tw + (int)(lane % (uint32_t)g.tw);
+        int y = (int)(tile / (uint32_t)g.tiles_x) * g.th + (int)(lane / (uint32_t)g.tw);
+        pixel_index[k] = (tile < (uint32_t)g.n_tiles && x < g.W && y < g.H) ? (int64_t)y * g.W + x : -1;
+    }
+    return RT_OK;
+}
+
+static int resolve_settings(rt_ctx *ctx, const rt_render_params *p, int32_t &sh, int32_t &rec) {
+    sh = p->sh_rays == RT_USE_SCENE_VALUE ? ctx->host.sh_rays : p->sh_rays;
+    rec = p->rec_max == RT_USE_SCENE_VALUE ? ctx->host.rec_max : p->rec_max;
+    if (sh < 1 && ctx->S.n_shadow_lights > 0) return fail(ctx, RT_ERR_INVALID_ARG, "root_number_shadow_rays must be >= 1");
+    if (sh > 1024) return fail(ctx, RT_ERR_UNSUPPORTED, "root_number_shadow_rays > 1024");
+    if (rec > RT_MAX_LEVELS - 2) return fail(ctx, RT_ERR_UNSUPPORTED, "max_recursions > 62");
+    return RT_OK;
+}
+
+// enqueue levels 0..rec on the stream; queue 0 must hold the level-0 rays
+static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, int32_t rec, int32_t *d_ids, hipStream_t st) {
+    LevelParams lp{};
+    lp.sh_rays = sh; lp.jitter = p->jitter; lp.seed = p->seed; lp.cap = (uint32_t)ctx->cap; lp.flags = p->flags;
+    dim3 grid(ctx->grid), block(RT_BLOCK);
+    for (int level = 0; level <= rec; ++level) {
+        lp.level = level;
+        lp.last_level = (level == rec) ? 1 : 0;
+        RayQ &qc = ctx->q[level & 1], &qn = ctx->q[(level + 1) & 1];
+        hipLaunchKernelGGL(k_intersect, grid, block, 0, st, ctx->S, lp, qc, ctx->hb, ctx->ctl, ctx->fb, d_ids);
+        if (ctx->S.n_shadow_lights > 0)
+            hipLaunchKernelGGL(k_shadow, grid, block, 0, st, ctx->S, lp, qc, ctx->hb, ctx->ctl);
+        hipLaunchKernelGGL(k_shade, grid, block, 0, st, ctx->S, lp, qc, qn, ctx->hb, ctx->ctl, ctx->fb);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+extern "C" int rt_render_device(rt_ctx *ctx, const rt_render_params *p, float *d_rgb, uint8_t *d_rgb8, int32_t *d_ids,
+                                void *stream) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    TileGeom g;
+    std::string why;
+    if (int rc = tile_geom(p, g, why)) return fail(ctx, rc, why);
+    int32_t sh, rec;
+    if (int rc = resolve_settings(ctx, p, sh, rec)) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    uint64_t need = g.slots > g.out_slots ? g.slots : g.out_slots;
+    if (int rc = ensure_frame(ctx, need)) return rc;
+
+    GenParams gp{};
+    const rt_scene_desc &s = ctx->host;
+    // ray_functions.py:17-25 (host, once per frame)
+    double w = s.cam_screen_width;
+    double h = w / g.W * g.H;
+    gp.hg = h / g.H;
+    gp.wg = w / g.W;
+    for (int k = 0; k < 3; ++k) {
+        gp.pos[k] = s.cam_pos[k]; gp.X[k] = s.cam_x[k]; gp.Y[k] = s.cam_y[k];
+        double center = s.cam_pos[k] + s.cam_z[k] * s.cam_screen_distance;
+        gp.p00[k] = (center + ((h - gp.hg) / 2 * s.cam_y[k])) - ((w - gp.wg) / 2 * s.cam_x[k]);
+    }
+    gp.W = g.W; gp.H = g.H; gp.tiles_x = g.tiles_x; gp.n_tiles = g.n_tiles; gp.rank = g.rank; gp.world = g.world;
+    gp.tw = g.tw; gp.th = g.th; gp.n_slots = (uint32_t)g.slots;
+
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->ctl, 0, sizeof(FrameCtl), st));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->fb, 0, g.out_slots * 3 * sizeof(double), st));
+    if (d_ids) HIP_TRY(ctx, hipMemsetAsync(d_ids, 0, g.out_slots * sizeof(int32_t), st));
+    dim3 grid(ctx->grid), block(RT_BLOCK);
+    if (rec < 0) {
+        // ray_tracer.py:62-63: everything is background; expressed as a frame with no levels
+        std::vector<double> bgfill(g.out_slots * 3);
+        for (uint64_t k = 0; k < g.out_slots; ++k) for (int c = 0; c < 3; ++c) bgfill[3 * k + c] = s.background[c];
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->fb, bgfill.data(), bgfill.size() * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+    } else {
+        hipLaunchKernelGGL(k_gen, grid, block, 0, st, gp, ctx->q[0], ctx->ctl);
+        if (int rc = enqueue_levels(ctx, p, sh, rec, d_ids, st)) return rc;
+    }
+    if (d_rgb || d_rgb8) hipLaunchKernelGGL(k_resolve, grid, block, 0, st, ctx->fb, g.out_slots * 3, d_rgb, d_rgb8);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctl, ctx->ctl, sizeof(FrameCtl), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->frame_pending = true;
+    ctx->last = *p; ctx->last_sh = sh; ctx->last_rec = rec; ctx->last_slots = g.slots;
+    return RT_OK;
+}
+
+extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    ctx->frame_pending = false;
+    const FrameCtl &c = *ctx->h_ctl;
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->primary_rays = (int64_t)c.primary_rays;
+        stats->reflect_rays = (int64_t)c.reflect_rays;
+        stats->transmit_rays = (int64_t)c.transmit_rays;
+        int64_t hits = 0, levels = 0, maxq = 0;
+        for (int l = 0; l <= ctx->last_rec && l < RT_MAX_LEVELS; ++l) {
+            hits += c.n_hits[l];
+            if (c.n_rays[l]) levels = l + 1;
+            if ((int64_t)c.n_rays[l] > maxq) maxq = c.n_rays[l];
+        }
+        stats->hits = hits;
+        stats->levels = levels;
+        stats->max_queue = maxq;
+        stats->shadow_rays = hits * (int64_t)ctx->S.n_shadow_lights * ctx->last_sh * ctx->last_sh;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) stats->ms_total = ms;
+    }
+    if (c.overflow) {
+        ctx->growth *= 2.0;   // the next frame gets larger queues
+        return fail(ctx, RT_ERR_QUEUE_OVERFLOW, "secondary-ray queue overflow; queue growth factor doubled, render again");
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_render(rt_ctx *ctx, const rt_render_params *p, float *rgb_out, uint8_t *rgb8_out, int32_t *ids_out,
+                         rt_stats *stats) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    TileGeom g;
+    std::string why;
+    if (int rc = tile_geom(p, g, why)) return fail(ctx, rc, why);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float *d_rgb = nullptr;
+    uint8_t *d_rgb8 = nullptr;
+    int32_t *d_ids = nullptr;
+    int rc = RT_OK;
+    auto cleanup = [&]() {
+        if (d_rgb) (void)hipFree(d_rgb);
+        if (d_rgb8) (void)hipFree(d_rgb8);
+        if (d_ids) (void)hipFree(d_ids);
+    };
+#define TRY_R(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+    if (rgb_out) TRY_R(hipMalloc((void **)&d_rgb, g.out_slots * 3 * sizeof(float)));
+    if (rgb8_out || !rgb_out) TRY_R(hipMalloc((void **)&d_rgb8, g.out_slots * 3));
+    if (ids_out) TRY_R(hipMalloc((void **)&d_ids, g.out_slots * sizeof(int32_t)));
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        rc = rt_render_device(ctx, p, d_rgb, d_rgb8, d_ids, nullptr);
+        if (rc != RT_OK) break;
+        rc = rt_sync_stats(ctx, stats);
+        if (rc != RT_ERR_QUEUE_OVERFLOW) break;
+    }
+    if (rc == RT_OK) {
+        if (rgb_out) TRY_R(hipMemcpy(rgb_out, d_rgb, g.out_slots * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        if (rgb8_out) TRY_R(hipMemcpy(rgb8_out, d_rgb8, g.out_slots * 3, hipMemcpyDeviceToHost));
+        if (ids_out) TRY_R(hipMemcpy(ids_out, d_ids, g.out_slots * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+#undef TRY_R
+    cleanup();
+    return rc;
+}
+
+extern "C" int rt_trace(rt_ctx *ctx, const rt_render_params *p, const double *origins, const double *directions,
+                        int64_t n, double *rgb_out, rt_stats *stats) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (!p || !origins || !directions || !rgb_out || n < 0) return fail(ctx, RT_ERR_INVALID_ARG, "NULL argument or negative n");
+    if (n == 0) return RT_OK;
+    if ((uint64_t)n > 0xFFFFFFF0ull / 4) return fail(ctx, RT_ERR_UNSUPPORTED, "too many rays in one batch");
+    int32_t sh, rec;
+    if (int rc = resolve_settings(ctx, p, sh, rec)) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    double *d_o = nullptr, *d_d = nullptr;
+    int rc = RT_OK;
+    auto cleanup = [&]() {
+        if (d_o) (void)hipFree(d_o);
+        if (d_d) (void)hipFree(d_d);
+    };
+#define TRY_T(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+    TRY_T(hipMalloc((void **)&d_o, (size_t)n * 3 * sizeof(double)));
+    TRY_T(hipMalloc((void **)&d_d, (size_t)n * 3 * sizeof(double)));
+    TRY_T(hipMemcpy(d_o, origins, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice));
+    TRY_T(hipMemcpy(d_d, directions, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice));
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        rc = ensure_frame(ctx, (uint64_t)n);
+        if (rc != RT_OK) break;
+        TRY_T(hipEventRecord(ctx->ev0, st));
+        TRY_T(hipMemsetAsync(ctx->ctl, 0, sizeof(FrameCtl), st));
+        TRY_T(hipMemsetAsync(ctx->fb, 0, (size_t)n * 3 * sizeof(double), st));
+        if (rec < 0) {
+            std::vector<double> bgfill((size_t)n * 3);
+            for (int64_t k = 0; k < n; ++k) for (int c = 0; c < 3; ++c) bgfill[3 * k + c] = ctx->host.background[c];
+            TRY_T(hipMemcpy(ctx->fb, bgfill.data(), bgfill.size() * sizeof(double), hipMemcpyHostToDevice));
+        } else {
+            hipLaunchKernelGGL(k_load_rays, dim3(ctx->grid), dim3(RT_BLOCK), 0, st, d_o, d_d, (uint32_t)n, ctx->q[0], ctx->ctl);
+            rc = enqueue_levels(ctx, p, sh, rec, nullptr, st);
+            if (rc != RT_OK) break;
+        }
+        TRY_T(hipMemcpyAsync(ctx->h_ctl, ctx->ctl, sizeof(FrameCtl), hipMemcpyDeviceToHost, st));
+        TRY_T(hipEventRecord(ctx->ev1, st));
+        ctx->last = *p; ctx->last_sh = sh; ctx->last_rec = rec; ctx->last_slots = (uint64_t)n;
+        rc = rt_sync_stats(ctx, stats);
+        if (rc != RT_ERR_QUEUE_OVERFLOW) break;
+    }
+    if (rc == RT_OK) TRY_T(hipMemcpy(rgb_out, ctx->fb, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+#undef TRY_T
+    cleanup();
+    return rc;
+}
+
+extern "C" int rt_intersect(rt_ctx *ctx, const double *origins, const double *directions, int64_t n, double *points_out,
+                            int64_t *ids_out) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (!origins || !directions || !points_out || !ids_out || n < 0) return fail(ctx, RT_ERR_INVALID_ARG, "NULL argument or negative n");
+    if (n == 0) return RT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    double *d_o = nullptr, *d_d = nullptr, *d_p = nullptr;
+    int64_t *d_i = nullptr;
+    auto cleanup = [&]() {
+        if (d_o) (void)hipFree(d_o);
+        if (d_d) (void)hipFree(d_d);
+        if (d_p) (void)hipFree(d_p);
+        if (d_i) (void)hipFree(d_i);
+    };
+#define TRY_I(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+    size_t vb = (size_t)n * 3 * sizeof(double);
+    TRY_I(hipMalloc((void **)&d_o, vb));
+    TRY_I(hipMalloc((void **)&d_d, vb));
+    TRY_I(hipMalloc((void **)&d_p, vb));
+    TRY_I(hipMalloc((void **)&d_i, (size_t)n * sizeof(int64_t)));
+    TRY_I(hipMemcpy(d_o, origins, vb, hipMemcpyHostToDevice));
+    TRY_I(hipMemcpy(d_d, directions, vb, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_intersect_only, dim3(ctx->grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->S, d_o, d_d, (uint64_t)n, d_p, d_i);
+    TRY_I(hipGetLastError());
+    TRY_I(hipStreamSynchronize(ctx->stream));
+    TRY_I(hipMemcpy(points_out, d_p, vb, hipMemcpyDeviceToHost));
+    TRY_I(hipMemcpy(ids_out, d_i, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost));
+#undef TRY_I
+    cleanup();
+    return RT_OK;
+}
+
+extern "C" int rt_deinterleave_u8(rt_ctx *ctx, const rt_render_params *p, const uint8_t *d_packed, int64_t stride_bytes,
+                                  uint8_t *d_image, void *stream) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    TileGeom g;
+    std::string why;
+    if (int rc = tile_geom(p, g, why)) return fail(ctx, rc, why);
+    if (!d_packed || !d_image) return fail(ctx, RT_ERR_INVALID_ARG, "NULL buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    hipLaunchKernelGGL(k_deinterleave_u8, dim3(ctx->grid), dim3(RT_BLOCK), 0, st, d_packed, stride_bytes, d_image, g.W, g.H,
+                       g.tw, g.th, g.tiles_x, g.n_tiles, g.world, g.tiles_per_rank);
+    HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+// ---- unit entry points: one primitive / one box against a ray batch (kernel-level parity) ----
+static int unit_run(int device, const double *in_a, const double *in_b, int64_t n, size_t out_elems_per_ray,
+                    void (*launch)(const double *, const double *, uint64_t, void *, void *, const void *),
+                    const void *extra, void *out_a, size_t out_a_bytes_per_ray, void *out_b, size_t out_b_bytes_per_ray) {
+    (void)out_elems_per_ray;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device");
+    if (n <= 0) return RT_OK;
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, RT_ERR_HIP, "hipSetDevice failed");
+    double *d_a = nullptr, *d_b = nullptr;
+    void *d_oa = nullptr, *d_ob = nullptr;
+    size_t vb = (size_t)n * 3 * sizeof(double);
+    int rc = RT_OK;
+    hipError_t e = hipSuccess;
+    if (in_a && (e = hipMalloc((void **)&d_a, vb)) == hipSuccess) e = hipMemcpy(d_a, in_a, vb, hipMemcpyHostToDevice);
+    if (e == hipSuccess && in_b && (e = hipMalloc((void **)&d_b, vb)) == hipSuccess) e = hipMemcpy(d_b, in_b, vb, hipMemcpyHostToDevice);
+    if (e == hipSuccess && out_a) e = hipMalloc(&d_oa, (size_t)n * out_a_bytes_per_ray);
+    if (e == hipSuccess && out_b) e = hipMalloc(&d_ob, (size_t)n * out_b_bytes_per_ray);
+    if (e == hipSuccess) {
+        launch(d_a, d_b, (uint64_t)n, d_oa, d_ob, extra);
+        e = hipDeviceSynchronize();
+    }
+    if (e == hipSuccess && out_a) e = hipMemcpy(out_a, d_oa, (size_t)n * out_a_bytes_per_ray, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && out_b) e = hipMemcpy(out_b, d_ob, (size_t)n * out_b_bytes_per_ray, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(nullptr, RT_ERR_HIP, std::string("unit kernel: ") + hipGetErrorString(e));
+    if (d_a) (void)hipFree(d_a);
+    if (d_b) (void)hipFree(d_b);
+    if (d_oa) (void)hipFree(d_oa);
+    if (d_ob) (void)hipFree(d_ob);
+    return rc;
+}
+
+struct UnitExtra {
+    int kind;
+    int outside_only;
+    double *d_par;
+};
+
+static double *unit_params(const double *par, int n) {
+    double *d = nullptr;
+    if (hipMalloc((void **)&d, n * sizeof(double)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, par, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    return d;
+}
+
+extern "C" int rt_unit_prim_intersect(int device, int kind, const double *params12, const double *origins,
+                                      const double *directions, int64_t n, double *points_out) {
+    if (!params12 || !origins || !directions || !points_out) return fail(nullptr, RT_ERR_INVALID_ARG, "NULL argument");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device");
+    UnitExtra ex{kind, 0, unit_params(params12, 12)};
+    if (!ex.d_par) return fail(nullptr, RT_ERR_HIP, "parameter upload failed");
+    int rc = unit_run(device, origins, directions, n, 3,
+                      [](const double *o, const double *d, uint64_t nn, void *oa, void *, const void *x) {
+                          const UnitExtra *e = (const UnitExtra *)x;
+                          hipLaunchKernelGGL(k_unit_prim, dim3(256), dim3(256), 0, 0, e->kind, e->d_par, o, d, nn, (double *)oa);
+                      },
+                      &ex, points_out, 3 * sizeof(double), nullptr, 0);
+    (void)hipFree(ex.d_par);
+    return rc;
+}
+
+extern "C" int rt_unit_prim_normals(int device, int kind, const double *params12, const double *points, int64_t n,
+                                    double *normals_out) {
+    if (!params12 || !points || !normals_out) return fail(nullptr, RT_ERR_INVALID_ARG, "NULL argument");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device");
+    UnitExtra ex{kind, 0, unit_params(params12, 12)};
+    if (!ex.d_par) return fail(nullptr, RT_ERR_HIP, "parameter upload failed");
+    int rc = unit_run(device, points, nullptr, n, 3,
+                      [](const double *pts, const double *, uint64_t nn, void *oa, void *, const void *x) {
+                          const UnitExtra *e = (const UnitExtra *)x;
+                          hipLaunchKernelGGL(k_unit_normals, dim3(256), dim3(256), 0, 0, e->kind, e->d_par, pts, nn, (double *)oa);
+                      },
+                      &ex, normals_out, 3 * sizeof(double), nullptr, 0);
+    (void)hipFree(ex.d_par);
+    return rc;
+}
+
+extern "C" int rt_unit_slab_mask(int device, const double *lo, const double *hi, int outside_only, const double *origins,
+                                 const double *directions, int64_t n, uint8_t *mask_out, double *t_near_out) {
+    if (!lo || !hi || !origins || !directions || !mask_out || !t_near_out) return fail(nullptr, RT_ERR_INVALID_ARG, "NULL argument");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device");
+    double par[6] = {lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]};
+    UnitExtra ex{0, outside_only, unit_params(par, 6)};
+    if (!ex.d_par) return fail(nullptr, RT_ERR_HIP, "parameter upload failed");
+    int rc = unit_run(device, origins, directions, n, 1,
+                      [](const double *o, const double *d, uint64_t nn, void *oa, void *ob, const void *x) {
+                          const UnitExtra *e = (const UnitExtra *)x;
+                          hipLaunchKernelGGL(k_unit_slab, dim3(256), dim3(256), 0, 0, e->d_par, e->d_par + 3, e->outside_only, o, d, nn,
+                                             (uint8_t *)oa, (double *)ob);
+                      },
+                      &ex, mask_out, 1, t_near_out, sizeof(double));
+    (void)hipFree(ex.d_par);
+    return rc;
+}
+
+// get_initial_rays (ray_functions.py:7-43) as a standalone query: sources/directions [W*H*3] float64, row-major
+extern "C" int rt_initial_rays(rt_ctx *ctx, int width, int height, double *sources_out, double *directions_out) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (width <= 0 || height <= 0 || !sources_out || !directions_out) return fail(ctx, RT_ERR_INVALID_ARG, "bad argument");
+    rt_render_params p{};
+    p.width = width; p.height = height; p.world = 1; p.tile_w = 8; p.tile_h = 8;
+    TileGeom g;
+    std::string why;
+    if (int rc = tile_geom(&p, g, why)) return fail(ctx, rc, why);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = ensure_frame(ctx, g.slots > g.out_slots ? g.slots : g.out_slots)) return rc;
+    GenParams gp{};
+    const rt_scene_desc &s = ctx->host;
+    double w = s.cam_screen_width;
+    double h = w / g.W * g.H;
+    gp.hg = h / g.H;
+    gp.wg = w / g.W;
+    for (int k = 0; k < 3; ++k) {
+        gp.pos[k] = s.cam_pos[k]; gp.X[k] = s.cam_x[k]; gp.Y[k] = s.cam_y[k];
+        double center = s.cam_pos[k] + s.cam_z[k] * s.cam_screen_distance;
+        gp.p00[k] = (center + ((h - gp.hg) / 2 * s.cam_y[k])) - ((w - gp.wg) / 2 * s.cam_x[k]);
+    }
+    gp.W = g.W; gp.H = g.H; gp.tiles_x = g.tiles_x; gp.n_tiles = g.n_tiles; gp.rank = 0; gp.world = 1;
+    gp.tw = g.tw; gp.th = g.th; gp.n_slots = (uint32_t)g.slots;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->ctl, 0, sizeof(FrameCtl), st));
+    hipLaunchKernelGGL(k_gen, dim3(ctx->grid), dim3(RT_BLOCK), 0, st, gp, ctx->q[0], ctx->ctl);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    uint64_t ns = g.slots;
+    std::vector<double> buf(ns * 6);
+    std::vector<uint32_t> slot(ns);
+    RayQ &q = ctx->q[0];
+    double *src[6] = {q.ox, q.oy, q.oz, q.dx, q.dy, q.dz};
+    for (int c = 0; c < 6; ++c) HIP_TRY(ctx, hipMemcpy(buf.data() + c * ns, src[c], ns * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(slot.data(), q.slot, ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (uint64_t k = 0; k < ns; ++k) {
+        if (slot[k] == RT_INVALID_SLOT) continue;
+        for (int c = 0; c < 3; ++c) {
+            sources_out[3ull * slot[k] + c] = buf[c * ns + k];
+            directions_out[3ull * slot[k] + c] = buf[(3 + c) * ns + k];
+        }
+    }
+    return RT_OK;
+}

@@ -1,0 +1,195 @@
+"""ctypes binding of csrc/librt_amd.so (the C-ABI of include/rt_amd.h).
+
+There is no CPU fallback: if the library is missing or no GPU is visible every
+call raises.  `python __graft_entry__.py` (or `make -C ray-tracing_amd/csrc`)
+builds the library in-tree.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_PKG = os.path.dirname(os.path.abspath(abi.__file__))
+LIB_PATH = os.path.join(_PKG, "csrc", "librt_amd.so")
+_LIB = None
+
+EXPORTS = ("rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_tile_pixels", "rt_tile_layout",
+           "rt_render", "rt_render_device", "rt_sync_stats", "rt_trace", "rt_intersect", "rt_deinterleave_u8",
+           "rt_initial_rays", "rt_unit_prim_intersect", "rt_unit_prim_normals", "rt_unit_slab_mask")
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("%s (%d): %s" % (abi.STATUS_NAMES.get(code, "RT_ERR"), code, message))
+        self.code = code
+
+
+def lib():
+    """Load the HIP library; raises (never falls back) when it is not built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s is missing - build it with `python __graft_entry__.py` or "
+                               "`make -C ray-tracing_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.rt_last_error.restype = C.c_char_p
+        L.rt_last_error.argtypes = [C.c_void_p]
+        L.rt_tile_pixels.restype = C.c_int64
+        L.rt_create.argtypes = [C.POINTER(abi.SceneDesc), C.c_int, C.POINTER(C.c_void_p)]
+        L.rt_destroy.argtypes = [C.c_void_p]
+        L.rt_render.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.POINTER(abi.Stats)]
+        L.rt_render_device.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]
+        L.rt_sync_stats.argtypes = [C.c_void_p, C.POINTER(abi.Stats)]
+        L.rt_trace.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_void_p, C.c_int64,
+                               C.c_void_p, C.POINTER(abi.Stats)]
+        L.rt_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.rt_deinterleave_u8.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_int64, C.c_void_p,
+                                         C.c_void_p]
+        L.rt_initial_rays.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.rt_tile_layout.argtypes = [C.POINTER(abi.RenderParams), C.c_void_p]
+        L.rt_tile_pixels.argtypes = [C.POINTER(abi.RenderParams)]
+        L.rt_unit_prim_intersect.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                             C.c_void_p]
+        L.rt_unit_prim_normals.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.rt_unit_slab_mask.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
+                                        C.c_void_p, C.c_void_p]
+        if L.rt_abi_version() != abi.RT_AMD_ABI_VERSION:
+            raise RuntimeError("librt_amd.so ABI version mismatch")
+        _LIB = L
+    return _LIB
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _check(code, ctx=None):
+    if code != abi.RT_OK:
+        msg = lib().rt_last_error(ctx)
+        raise NativeError(code, msg.decode() if msg else "")
+
+
+def tile_pixels(params):
+    n = lib().rt_tile_pixels(C.byref(params))
+    if n < 0:
+        raise NativeError(-1, "bad render params")
+    return int(n)
+
+
+def tile_layout(params):
+    pix = np.empty(tile_pixels(params), dtype=np.int64)
+    _check(lib().rt_tile_layout(C.byref(params), pix.ctypes.data))
+    return pix
+
+
+class Context:
+    """A scene resident on one GPU (rt_create / rt_destroy)."""
+
+    def __init__(self, packed, device=0):
+        self._h = C.c_void_p()
+        self.packed = packed        # keeps the host arrays alive
+        self.device = device
+        _check(lib().rt_create(C.byref(packed.desc), int(device), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().rt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- whole frames ---------------------------------------------------------------------
+    def render(self, params, want_rgb=True, want_ids=True):
+        """Blocking render into host arrays: dict(rgb float32 (n,3), rgb8 uint8 (n,3), ids int32 (n,), stats)."""
+        n = tile_pixels(params)
+        rgb = np.empty((n, 3), dtype=np.float32) if want_rgb else None
+        rgb8 = np.empty((n, 3), dtype=np.uint8)
+        ids = np.empty(n, dtype=np.int32) if want_ids else None
+        st = abi.Stats()
+        _check(lib().rt_render(self._h, C.byref(params), rgb.ctypes.data if want_rgb else None, rgb8.ctypes.data,
+                               ids.ctypes.data if want_ids else None, C.byref(st)), self._h)
+        return dict(rgb=rgb, rgb8=rgb8, ids=ids, stats=st.as_dict())
+
+    def render_device(self, params, d_rgb=0, d_rgb8=0, d_ids=0, stream=0):
+        """Enqueue a frame; outputs are raw device pointers (ints, 0 = not wanted); returns immediately."""
+        _check(lib().rt_render_device(self._h, C.byref(params), C.c_void_p(d_rgb or None), C.c_void_p(d_rgb8 or None),
+                                      C.c_void_p(d_ids or None), C.c_void_p(stream or None)), self._h)
+
+    def sync_stats(self):
+        st = abi.Stats()
+        _check(lib().rt_sync_stats(self._h, C.byref(st)), self._h)
+        return st.as_dict()
+
+    def deinterleave_u8(self, params, d_packed, stride_bytes, d_image, stream=0):
+        _check(lib().rt_deinterleave_u8(self._h, C.byref(params), C.c_void_p(d_packed), int(stride_bytes),
+                                        C.c_void_p(d_image), C.c_void_p(stream or None)), self._h)
+
+    # -- ray batches ----------------------------------------------------------------------
+    def trace(self, params, origins, directions):
+        """ray_tracing() for an arbitrary batch -> ((N,3) float64 unclipped colours, stats)."""
+        o, d = _f64(origins), _f64(directions)
+        if o.shape != d.shape or o.ndim != 2 or o.shape[1] != 3:
+            raise ValueError("origins/directions must both be (N,3)")
+        out = np.empty_like(o)
+        st = abi.Stats()
+        _check(lib().rt_trace(self._h, C.byref(params), o.ctypes.data, d.ctypes.data, o.shape[0], out.ctypes.data,
+                              C.byref(st)), self._h)
+        return out, st.as_dict()
+
+    def intersect(self, origins, directions):
+        """BSPNode.intersect_vectorize -> ((N,3) float64 points, (N,) int64 ids, 0 = miss)."""
+        o, d = _f64(origins), _f64(directions)
+        if o.shape != d.shape or o.ndim != 2 or o.shape[1] != 3:
+            raise ValueError("ray_sources/ray_directions must both be (N,3)")
+        pts = np.empty_like(o)
+        ids = np.empty(o.shape[0], dtype=np.int64)
+        _check(lib().rt_intersect(self._h, o.ctypes.data, d.ctypes.data, o.shape[0], pts.ctypes.data,
+                                  ids.ctypes.data), self._h)
+        return pts, ids
+
+    def initial_rays(self, width, height):
+        src = np.empty((width * height, 3))
+        dirs = np.empty((width * height, 3))
+        _check(lib().rt_initial_rays(self._h, int(width), int(height), src.ctypes.data, dirs.ctypes.data), self._h)
+        return src, dirs
+
+
+# -- single-primitive kernels (host mirror's surface.intersect_vectorized etc.) ----------------
+def prim_intersect(kind, params12, origins, directions, device=0):
+    o, d, par = _f64(origins), _f64(directions), _f64(params12)
+    out = np.empty_like(o)
+    _check(lib().rt_unit_prim_intersect(device, int(kind), par.ctypes.data, o.ctypes.data, d.ctypes.data, o.shape[0],
+                                        out.ctypes.data))
+    return out
+
+
+def prim_normals(kind, params12, points, device=0):
+    p, par = _f64(points), _f64(params12)
+    out = np.empty_like(p)
+    _check(lib().rt_unit_prim_normals(device, int(kind), par.ctypes.data, p.ctypes.data, p.shape[0],
+                                      out.ctypes.data))
+    return out
+
+
+def slab_mask(origins, directions, bounds_min, bounds_max, outside_hits_only=True, device=0):
+    o, d = _f64(origins), _f64(directions)
+    lo, hi = _f64(bounds_min), _f64(bounds_max)
+    mask = np.empty(o.shape[0], dtype=np.uint8)
+    tn = np.empty(o.shape[0])
+    _check(lib().rt_unit_slab_mask(device, lo.ctypes.data, hi.ctypes.data, 1 if outside_hits_only else 0,
+                                   o.ctypes.data, d.ctypes.data, o.shape[0], mask.ctypes.data, tn.ctypes.data))
+    return mask.astype(bool)[:, None], tn[:, None]
