@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Headline benchmark (contract in the task statement, metric in BASELINE.json).
+
+A step = one frame of the hot path: camera rays -> nearest hits -> N^2 soft
+shadows + Phong -> reflection / transparency recursion -> 8-bit framebuffer, all
+inputs (scene, BSP tree) resident in HBM before the timed region.
+
+  N = 1 : synthetic 10k-sphere scene (tools/gen_scene.py synth, grid 100, seed 1234),
+          1920x1080, 5x5 shadow rays, recursion 5  (BASELINE.json configs[2])
+  N > 1 : the same scene at 3840x2160, 8x8 tiles interleaved over the ranks, packed
+          uint8 tiles gathered to rank 0 with RCCL and de-interleaved there
+          (configs[3]); total work is fixed for N in {2,4,8}  -> "strong".
+
+value = rays handed to the nearest-hit query per second, counted exactly as the
+reference counts them (every ray given to BSPNode.intersect_vectorize), whole job.
+
+Rank 0 prints ONE JSON line with the roofline of the dominant kernel (k_shadow)
+and the CPU baseline (the float64 oracle, timed on a bounded sub-sampled frame).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+# algorithmic flops per unit of work, SURVEY.md §8(d)
+F_NODE, F_BOX, F_SPHERE, F_PLANE = 24, 24, 33, 14
+F_SHADOW_SETUP, F_SHADE, F_RAY_SETUP, F_RAYGEN = 40, 50, 12, 25
+PEAK_FP32_VALU_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz
+
+
+def build_scene(workload):
+    import ray_tracing_amd  # noqa: F401
+    import gen_scene
+    from ray_tracing_amd.render import Scene
+    if workload == "synth10k":
+        text = gen_scene.synth_spheres(100, 1234, 5, 5)
+    elif workload == "synth400":
+        text = gen_scene.synth_spheres(20, 1234, 5, 5)
+    elif workload == "pool":
+        return Scene.from_file(os.path.join(ROOT, "tests", "golden", "scenes", "pool.txt"))
+    elif workload == "original":
+        return Scene.from_file(os.path.join(ROOT, "tests", "golden", "scenes", "original.txt"))
+    else:
+        raise SystemExit("unknown workload " + workload)
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        f.write(text)
+        path = f.name
+    try:
+        return Scene.from_file(path)
+    finally:
+        os.unlink(path)
+
+
+def algorithmic_flops(cnt, n_lights, n_planes):
+    """flops(frame) and the share of the shadow rays, from the oracle's traversal counters."""
+    rays = cnt["rays"]
+    frame = (rays * (F_RAY_SETUP + F_PLANE * n_planes) + F_NODE * cnt["node_tests"] + F_SPHERE * cnt["sphere_tests"]
+             + F_BOX * cnt["box_tests"] + F_SHADOW_SETUP * cnt["shadow_rays"] + F_SHADE * cnt["hits"] * n_lights
+             + F_RAYGEN * cnt["primary_rays"])
+    shadow = (cnt["shadow_rays"] * (F_RAY_SETUP + F_PLANE * n_planes + F_SHADOW_SETUP)
+              + F_NODE * cnt["shadow_node_tests"] + F_SPHERE * cnt["shadow_sphere_tests"]
+              + F_BOX * cnt["shadow_box_tests"])
+    return frame, shadow
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="synth10k")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--sh-rays", type=int, default=None)
+    ap.add_argument("--rec-max", type=int, default=None)
+    ap.add_argument("--no-jitter", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-div", type=int, default=4, help="CPU baseline renders (W/div)x(H/div)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the hot path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import ray_tracing_amd  # noqa: F401
+    from ray_tracing_amd import abi, native
+    from ray_tracing_amd.render import gather_packed
+
+    scene = build_scene(args.workload)
+    ctx = native.Context(scene.packed, device=local_rank)
+    W = args.width or (1920 if world == 1 else 3840)
+    H = args.height or (1080 if world == 1 else 2160)
+    jitter = not args.no_jitter
+
+    def params(seed, flags=0):
+        return abi.render_params(W, H, sh_rays=args.sh_rays, rec_max=args.rec_max, jitter=jitter, seed=seed, rank=rank,
+                                 world=world, flags=flags)
+
+    npix = native.tile_pixels(params(0))
+    local = torch.empty(npix * 3, dtype=torch.uint8, device=dev)
+    image = torch.empty(H * W * 3, dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
+    stream = torch.cuda.Stream(device=dev)
+
+    def step(i):
+        with torch.cuda.stream(stream):
+            p = params(1000 + i)
+            ctx.render_device(p, d_rgb8=local.data_ptr(), stream=stream.cuda_stream)
+            if world > 1:
+                gathered = gather_packed(local, rank, world, dst=0)          # the frame's one exchange step
+                if rank == 0:
+                    ctx.deinterleave_u8(p, gathered.data_ptr(), npix * 3, image.data_ptr(), stream=stream.cuda_stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # size the secondary-ray queues before anything is timed (an overflowing frame reports
+    # RT_ERR_QUEUE_OVERFLOW and doubles the growth factor for the next one)
+    for _ in range(6):
+        try:
+            with torch.cuda.stream(stream):
+                ctx.render_device(params(999), d_rgb8=local.data_ptr(), stream=stream.cuda_stream)
+            ctx.sync_stats()
+            break
+        except native.NativeError as e:
+            if e.code != -5:
+                raise
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    st = ctx.sync_stats()                       # counters of the last frame (ray counts do not depend on the seed)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    rays = torch.tensor([float(st["rays"])], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    rays_per_frame = float(rays.item())
+
+    # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream ----
+    roofline = None
+    cpu_baseline = None
+    prof = None
+    if rank == 0:
+        with torch.cuda.stream(stream):
+            ctx.render_device(params(1000, flags=abi.RT_FLAG_PROFILE), d_rgb8=local.data_ptr(), stream=stream.cuda_stream)
+        prof = ctx.sync_stats()
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        # oracle on a bounded sample: the same camera at (W/div)x(H/div); per-ray traversal statistics of the
+        # reference's algorithm (nodes visited, primitives tested) are resolution independent
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import orc
+        div = max(1, args.cpu_sample_div)
+        sw, sh_ = max(8, W // div), max(8, H // div)
+        threads = min(16, os.cpu_count() or 1)
+        sp = abi.render_params(sw, sh_, sh_rays=args.sh_rays, rec_max=args.rec_max, jitter=jitter, seed=1000)
+        c0 = time.perf_counter()
+        ref = orc.render(scene.packed, sp, threads=threads, want_f64=False)
+        cpu_s = time.perf_counter() - c0
+        cnt = ref["counters"]
+        n_lights, n_planes = scene.packed.desc.n_lights, scene.packed.desc.n_planes
+        frame_flops_s, shadow_flops_s = algorithmic_flops(cnt, n_lights, n_planes)
+        # scale the sample's per-ray figures to the GPU frame's exact ray counts (this rank's share)
+        flops_per_shadow_ray = shadow_flops_s / max(cnt["shadow_rays"], 1)
+        flops_per_ray = frame_flops_s / max(cnt["rays"], 1)
+        shadow_flops = flops_per_shadow_ray * prof["shadow_rays"]
+        frame_flops = flops_per_ray * prof["rays"]
+        ms_shadow = prof["ms_shadow"]
+        achieved = shadow_flops / (ms_shadow * 1e-3) / 1e12 if ms_shadow > 0 else 0.0
+        roofline = {
+            "bound": "valu", "kernel": "k_shadow", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": None,
+            "launches": prof["launches_per_family"], "kernel_ms_per_frame": round(ms_shadow, 3),
+            "algorithmic_flops_per_shadow_ray": round(flops_per_shadow_ray, 1),
+            "frame": {"algorithmic_flops_per_ray": round(flops_per_ray, 1),
+                      "achieved_tflops": round(frame_flops / (prof["ms_total"] * 1e-3) / 1e12, 3),
+                      "ms": {k: round(prof[k], 3) for k in ("ms_total", "ms_gen", "ms_intersect", "ms_shadow",
+                                                            "ms_shade", "ms_resolve")}},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            cpu_baseline = {"value": round(cnt["rays"] / cpu_s / 1e6, 3), "unit": "Mrays/s", "cores": threads,
+                            "kind": "port",
+                            "sample": "oracle/oracle.cpp (float64 restatement), same scene and settings at %dx%d "
+                                      "(1/%d of the pixels), %d rays in %.2f s" % (sw, sh_, div * div, cnt["rays"],
+                                                                                  cpu_s)}
+
+    if rank == 0:
+        value = rays_per_frame * args.steps / elapsed / 1e6
+        sh_used = args.sh_rays if args.sh_rays is not None else scene.settings.root_number_shadow_rays
+        rec_used = args.rec_max if args.rec_max is not None else scene.settings.max_recursions
+        line = {
+            "metric": "Mrays/s (rays handed to the nearest-hit query, whole job); frame time = ms_per_step",
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
+            "dtype": "f64 decisions + f64 shading (f32 only for culling)", "data": "synthetic",
+            "config": {"workload": "%s %dx%d, %dx%d shadow rays, recursion %d, jitter %s" % (
+                args.workload, W, H, sh_used, sh_used, rec_used, "on" if jitter else "off"),
+                "primitives": scene.packed.desc.n_spheres + scene.packed.desc.n_boxes + scene.packed.desc.n_planes,
+                "lights": scene.packed.desc.n_lights, "bsp_nodes": scene.packed.desc.n_nodes,
+                "rays_per_frame": int(rays_per_frame), "partition": "8x8 tiles interleaved over %d rank(s)" % world},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -135,6 +135,8 @@ typedef struct rt_render_params {
 
 #define RT_FLAG_EXACT_TRAVERSAL 1  /* diagnostic: visit nodes with the reference's float64 slab test only
                                       (no float32 culling, no pruning); results must be identical */
+#define RT_FLAG_PROFILE 2          /* bracket every kernel launch with HIP events on the launch stream and
+                                      report per-family device time in rt_stats (used by bench.py's roofline) */
 
 /* Work counters of the last frame (the Mrays/s numerator counts rays exactly as
  * the reference issues them to BSPNode.intersect_vectorize). */
@@ -144,7 +146,9 @@ typedef struct rt_stats {
     int64_t levels;              /* recursion levels that had live rays */
     int64_t max_queue;           /* largest ray queue of the frame */
     double ms_total;             /* device time of the frame (HIP events) */
-    double ms_intersect, ms_shadow, ms_shade; /* per kernel family, summed over levels */
+    double ms_intersect, ms_shadow, ms_shade; /* per kernel family, summed over levels (RT_FLAG_PROFILE only) */
+    double ms_gen, ms_resolve;   /* RT_FLAG_PROFILE only */
+    int64_t launches_per_family; /* RT_FLAG_PROFILE only: number of k_intersect (= k_shadow = k_shade) launches */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

@@ -68,7 +68,11 @@ inline double np_max(double a, double b) { return (std::isnan(a) || std::isnan(b
 struct Counters {
     int64_t primary = 0, shadow = 0, reflect = 0, transmit = 0;
     int64_t hits = 0, node_tests = 0, sphere_tests = 0, box_tests = 0, plane_tests = 0, shade_lights = 0;
+    /* share of the four test counters spent on shadow rays (subset of the totals above) */
+    int64_t sh_node_tests = 0, sh_sphere_tests = 0, sh_box_tests = 0, sh_plane_tests = 0;
     void add(const Counters &o) {
+        sh_node_tests += o.sh_node_tests; sh_sphere_tests += o.sh_sphere_tests; sh_box_tests += o.sh_box_tests;
+        sh_plane_tests += o.sh_plane_tests;
         primary += o.primary; shadow += o.shadow; reflect += o.reflect; transmit += o.transmit;
         hits += o.hits; node_tests += o.node_tests; sphere_tests += o.sphere_tests; box_tests += o.box_tests;
         plane_tests += o.plane_tests; shade_lights += o.shade_lights;
@@ -331,7 +335,10 @@ double shadow_factor(const Ctx &cx, int m, V3 L, V3 P, uint32_t pixel, uint32_t 
             V3 src, dir;
             shadow_ray(s, m, P, up, right, n, a, b, cx.jitter ? jit : nullptr, src, dir);
             c.shadow++;
+            const int64_t n0 = c.node_tests, s0 = c.sphere_tests, b0 = c.box_tests, p0 = c.plane_tests;
             Best h = nearest_hit(s, src, dir, c);
+            c.sh_node_tests += c.node_tests - n0; c.sh_sphere_tests += c.sphere_tests - s0;
+            c.sh_box_tests += c.box_tests - b0; c.sh_plane_tests += c.plane_tests - p0;
             double dd = norm(h.p - P);
             if (dd < EPSILON) lit++;
         }
@@ -456,14 +463,15 @@ void fill_counters(const Counters &c, int64_t *out) {
     out[0] = c.primary; out[1] = c.shadow; out[2] = c.reflect; out[3] = c.transmit; out[4] = c.hits;
     out[5] = c.node_tests; out[6] = c.sphere_tests; out[7] = c.box_tests; out[8] = c.plane_tests;
     out[9] = c.shade_lights;
+    out[10] = c.sh_node_tests; out[11] = c.sh_sphere_tests; out[12] = c.sh_box_tests; out[13] = c.sh_plane_tests;
 }
 
 }  // namespace
 
 extern "C" {
 
-/* counters_out[10]: primary, shadow, reflect, transmit rays, hits, node tests, sphere tests, box tests,
- * plane tests, (hit,light) shading terms */
+/* counters_out[14]: primary, shadow, reflect, transmit rays, hits, node tests, sphere tests, box tests,
+ * plane tests, (hit,light) shading terms, then the shadow-ray share of the four test counters */
 
 int orc_intersect(const rt_scene_desc *s, const double *o, const double *d, int64_t n, double *pts, int64_t *ids,
                   int64_t *counters_out, int threads) {

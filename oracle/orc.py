@@ -13,7 +13,8 @@ from ray_tracing_amd import abi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 COUNTER_NAMES = ("primary_rays", "shadow_rays", "reflect_rays", "transmit_rays", "hits", "node_tests",
-                 "sphere_tests", "box_tests", "plane_tests", "shade_lights")
+                 "sphere_tests", "box_tests", "plane_tests", "shade_lights", "shadow_node_tests",
+                 "shadow_sphere_tests", "shadow_box_tests", "shadow_plane_tests")
 
 
 def build():
@@ -50,7 +51,7 @@ def intersect(packed, origins, directions, threads=0):
     n = o.shape[0]
     pts = np.empty((n, 3))
     ids = np.empty(n, dtype=np.int64)
-    cnt = np.zeros(10, dtype=np.int64)
+    cnt = np.zeros(14, dtype=np.int64)
     lib().orc_intersect(C.byref(packed.desc), _p(o), _p(d), C.c_int64(n), _p(pts), _p(ids, C.c_int64),
                         _p(cnt, C.c_int64), C.c_int(threads))
     return pts, ids, _counters(cnt)
@@ -62,7 +63,7 @@ def render(packed, params, threads=0, want_f64=True):
     rgb = np.empty((npix, 3)) if want_f64 else None
     rgb8 = np.empty((npix, 3), dtype=np.uint8)
     ids = np.empty(npix, dtype=np.int32)
-    cnt = np.zeros(10, dtype=np.int64)
+    cnt = np.zeros(14, dtype=np.int64)
     lib().orc_render(C.byref(packed.desc), C.byref(params), _p(rgb) if want_f64 else None, _p(rgb8, C.c_uint8),
                      _p(ids, C.c_int32), _p(cnt, C.c_int64), C.c_int(threads))
     return dict(rgb=rgb, rgb8=rgb8, ids=ids, counters=_counters(cnt))
@@ -72,7 +73,7 @@ def trace(packed, params, origins, directions, threads=0):
     o, d = _f64(origins), _f64(directions)
     n = o.shape[0]
     rgb = np.empty((n, 3))
-    cnt = np.zeros(10, dtype=np.int64)
+    cnt = np.zeros(14, dtype=np.int64)
     lib().orc_trace(C.byref(packed.desc), C.byref(params), _p(o), _p(d), C.c_int64(n), _p(rgb), _p(cnt, C.c_int64),
                     C.c_int(threads))
     return rgb, _counters(cnt)

@@ -6,6 +6,7 @@ RT_AMD_ABI_VERSION = 1
 RT_USE_SCENE_VALUE = -2147483648
 RT_SURF_BACKGROUND, RT_SURF_SPHERE, RT_SURF_BOX, RT_SURF_PLANE = 0, 1, 2, 3
 RT_FLAG_EXACT_TRAVERSAL = 1
+RT_FLAG_PROFILE = 2
 
 RT_OK = 0
 STATUS_NAMES = {0: "RT_OK", -1: "RT_ERR_INVALID_ARG", -2: "RT_ERR_NO_DEVICE", -3: "RT_ERR_HIP", -4: "RT_ERR_OOM",
@@ -49,6 +50,7 @@ class Stats(C.Structure):
         ("primary_rays", C.c_int64), ("shadow_rays", C.c_int64), ("reflect_rays", C.c_int64),
         ("transmit_rays", C.c_int64), ("hits", C.c_int64), ("levels", C.c_int64), ("max_queue", C.c_int64),
         ("ms_total", C.c_double), ("ms_intersect", C.c_double), ("ms_shadow", C.c_double), ("ms_shade", C.c_double),
+        ("ms_gen", C.c_double), ("ms_resolve", C.c_double), ("launches_per_family", C.c_int64),
     ]
 
     def as_dict(self):

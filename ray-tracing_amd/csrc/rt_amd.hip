@@ -541,6 +541,8 @@ struct rt_ctx {
     FrameCtl *ctl = nullptr;
     FrameCtl *h_ctl = nullptr;   // pinned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> prof_ev;     // RT_FLAG_PROFILE: [gen0, gen1, (i0,i1,s0,s1,h0,h1) per level ..., res0, res1]
+    int prof_levels = -1;                // levels bracketed in the last frame, -1 = not profiled
     bool frame_pending = false;
     rt_render_params last{};
     int32_t last_sh = 0, last_rec = 0;
@@ -775,6 +777,7 @@ extern "C" int rt_destroy(rt_ctx *ctx) {
     if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RT_OK;
@@ -878,19 +881,39 @@ static int resolve_settings(rt_ctx *ctx, const rt_render_params *p, int32_t &sh,
     return RT_OK;
 }
 
+static int prof_prepare(rt_ctx *ctx, int levels) {
+    size_t need = 4 + 6 * (size_t)levels;
+    while (ctx->prof_ev.size() < need) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->prof_ev.push_back(e);
+    }
+    ctx->prof_levels = levels;
+    return RT_OK;
+}
+#define PROF_MARK(idx) do { if (prof) HIP_TRY(ctx, hipEventRecord(ctx->prof_ev[(idx)], st)); } while (0)
+
 // enqueue levels 0..rec on the stream; queue 0 must hold the level-0 rays
 static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, int32_t rec, int32_t *d_ids, hipStream_t st) {
     LevelParams lp{};
     lp.sh_rays = sh; lp.jitter = p->jitter; lp.seed = p->seed; lp.cap = (uint32_t)ctx->cap; lp.flags = p->flags;
     dim3 grid(ctx->grid), block(RT_BLOCK);
+    const bool prof = (p->flags & RT_FLAG_PROFILE) != 0;
     for (int level = 0; level <= rec; ++level) {
         lp.level = level;
         lp.last_level = (level == rec) ? 1 : 0;
         RayQ &qc = ctx->q[level & 1], &qn = ctx->q[(level + 1) & 1];
+        const int e = 2 + 6 * level;
+        PROF_MARK(e + 0);
         hipLaunchKernelGGL(k_intersect, grid, block, 0, st, ctx->S, lp, qc, ctx->hb, ctx->ctl, ctx->fb, d_ids);
+        PROF_MARK(e + 1);
+        PROF_MARK(e + 2);
         if (ctx->S.n_shadow_lights > 0)
             hipLaunchKernelGGL(k_shadow, grid, block, 0, st, ctx->S, lp, qc, ctx->hb, ctx->ctl);
+        PROF_MARK(e + 3);
+        PROF_MARK(e + 4);
         hipLaunchKernelGGL(k_shade, grid, block, 0, st, ctx->S, lp, qc, qn, ctx->hb, ctx->ctl, ctx->fb);
+        PROF_MARK(e + 5);
     }
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
@@ -924,6 +947,9 @@ extern "C" int rt_render_device(rt_ctx *ctx, const rt_render_params *p, float *d
     gp.W = g.W; gp.H = g.H; gp.tiles_x = g.tiles_x; gp.n_tiles = g.n_tiles; gp.rank = g.rank; gp.world = g.world;
     gp.tw = g.tw; gp.th = g.th; gp.n_slots = (uint32_t)g.slots;
 
+    const bool prof = (p->flags & RT_FLAG_PROFILE) != 0 && rec >= 0;
+    ctx->prof_levels = -1;
+    if (prof) { if (int rc = prof_prepare(ctx, rec + 1)) return rc; }
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
     HIP_TRY(ctx, hipMemsetAsync(ctx->ctl, 0, sizeof(FrameCtl), st));
     HIP_TRY(ctx, hipMemsetAsync(ctx->fb, 0, g.out_slots * 3 * sizeof(double), st));
@@ -936,10 +962,14 @@ extern "C" int rt_render_device(rt_ctx *ctx, const rt_render_params *p, float *d
         HIP_TRY(ctx, hipMemcpyAsync(ctx->fb, bgfill.data(), bgfill.size() * sizeof(double), hipMemcpyHostToDevice, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
     } else {
+        PROF_MARK(0);
         hipLaunchKernelGGL(k_gen, grid, block, 0, st, gp, ctx->q[0], ctx->ctl);
+        PROF_MARK(1);
         if (int rc = enqueue_levels(ctx, p, sh, rec, d_ids, st)) return rc;
     }
+    PROF_MARK(2 + 6 * (rec + 1));
     if (d_rgb || d_rgb8) hipLaunchKernelGGL(k_resolve, grid, block, 0, st, ctx->fb, g.out_slots * 3, d_rgb, d_rgb8);
+    PROF_MARK(3 + 6 * (rec + 1));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctl, ctx->ctl, sizeof(FrameCtl), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
     HIP_TRY(ctx, hipGetLastError());
@@ -971,6 +1001,20 @@ extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
         stats->shadow_rays = hits * (int64_t)ctx->S.n_shadow_lights * ctx->last_sh * ctx->last_sh;
         float ms = 0;
         if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) stats->ms_total = ms;
+        if (ctx->prof_levels >= 0) {
+            auto span = [&](int a) {
+                float t = 0;
+                return hipEventElapsedTime(&t, ctx->prof_ev[a], ctx->prof_ev[a + 1]) == hipSuccess ? (double)t : 0.0;
+            };
+            stats->ms_gen = span(0);
+            for (int l = 0; l < ctx->prof_levels; ++l) {
+                stats->ms_intersect += span(2 + 6 * l);
+                stats->ms_shadow += span(4 + 6 * l);
+                stats->ms_shade += span(6 + 6 * l);
+            }
+            stats->ms_resolve = span(2 + 6 * ctx->prof_levels);
+            stats->launches_per_family = ctx->prof_levels;
+        }
     }
     if (c.overflow) {
         ctx->growth *= 2.0;   // the next frame gets larger queues
@@ -1048,7 +1092,10 @@ extern "C" int rt_trace(rt_ctx *ctx, const rt_render_params *p, const double *or
             TRY_T(hipMemcpy(ctx->fb, bgfill.data(), bgfill.size() * sizeof(double), hipMemcpyHostToDevice));
         } else {
             hipLaunchKernelGGL(k_load_rays, dim3(ctx->grid), dim3(RT_BLOCK), 0, st, d_o, d_d, (uint32_t)n, ctx->q[0], ctx->ctl);
-            rc = enqueue_levels(ctx, p, sh, rec, nullptr, st);
+            rt_render_params pp = *p;
+            pp.flags &= ~RT_FLAG_PROFILE;
+            ctx->prof_levels = -1;
+            rc = enqueue_levels(ctx, &pp, sh, rec, nullptr, st);
             if (rc != RT_OK) break;
         }
         TRY_T(hipMemcpyAsync(ctx->h_ctl, ctx->ctl, sizeof(FrameCtl), hipMemcpyDeviceToHost, st));
