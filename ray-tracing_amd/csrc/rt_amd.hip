@@ -27,6 +27,7 @@
 
 #include "../../include/rt_amd.h"
 #include "rt_device.hpp"
+#include "rt_fast.hpp"
 
 #define RT_BLOCK 256
 #define RT_MAX_LEVELS 64
@@ -56,6 +57,10 @@ struct HitBuf {          // per ray slot of the CURRENT queue
     int32_t *id;
     uint32_t *list;      // compacted indices of rays that hit something
     uint32_t *lit;       // [cap * n_shadow_lights] lit-sample counters
+};
+
+struct SegBuf {          // per (hit, shadow light): light-plane basis of Light.get_shadow_rays, computed once
+    double *ux, *uy, *uz, *rx, *ry, *rz, *cx, *cy, *cz;   // up, right, p00 (Light.py:257-260)
 };
 
 struct GenParams {
@@ -108,7 +113,7 @@ __device__ __forceinline__ void fb_add(double *fb, uint32_t slot, d3 c) {
 // first, over every node whose box passes the slab test -> leaf primitives in list order; a
 // candidate replaces the current best only when its Euclidean distance is STRICTLY smaller.
 // Pre-order layout + skip links make the left-first DFS a linear walk without a stack.
-__device__ __forceinline__ Hit nearest_hit(const DScene &S, d3 o, d3 d) {
+__device__ __noinline__ Hit nearest_hit_exact(const DScene &S, d3 o, d3 d) {
     Hit best;
     if (S.far_clip) {
         best.p = mk3(RT_MAX_RENDER_DISTANCE, RT_MAX_RENDER_DISTANCE, RT_MAX_RENDER_DISTANCE);
@@ -150,6 +155,29 @@ __device__ __forceinline__ Hit nearest_hit(const DScene &S, d3 o, d3 d) {
         i = i + 1;
     }
     return best;
+}
+
+__device__ __forceinline__ bool ray_is_tame(d3 o, d3 d) {
+    // the float32 culling assumes finite coordinates well inside the float range and away from the
+    // Background point (1e8,1e8,1e8); anything else takes the exact walk
+    double m = fmax(fmax(fabs(o.x), fabs(o.y)), fabs(o.z));
+    double n = fmax(fmax(fabs(d.x), fabs(d.y)), fabs(d.z));
+    return (m < 1e7) && (n < 1e7) && (n > 1e-30);
+}
+
+// nearest hit, fast path with exact fallback (ties between different primitives, wild rays, non-kd trees)
+template <bool FAST>
+__device__ __forceinline__ Hit nearest_hit(const DScene &S, const FastScene &F, uint2 *stk, d3 o, d3 d) {
+    if (FAST && ray_is_tame(o, d)) {
+        FastState st;
+        fast_nearest<RT_BLOCK>(S, F, stk, o, d, __int_as_float(0x7f800000), -dinf(), st);
+        if (!st.tie) {
+            if (st.best.id == 0 && S.far_clip)
+                st.best.p = mk3(RT_MAX_RENDER_DISTANCE, RT_MAX_RENDER_DISTANCE, RT_MAX_RENDER_DISTANCE);
+            return st.best;
+        }
+    }
+    return nearest_hit_exact(S, o, d);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -211,8 +239,11 @@ __global__ void __launch_bounds__(RT_BLOCK) k_load_rays(const double *o, const d
     }
 }
 
-__global__ void __launch_bounds__(RT_BLOCK) k_intersect(DScene S, LevelParams lp, RayQ q, HitBuf hb, FrameCtl *ctl,
-                                                        double *fb, int32_t *ids_out) {
+template <bool FAST>
+__global__ void __launch_bounds__(RT_BLOCK) k_intersect(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb,
+                                                        FrameCtl *ctl, double *fb, int32_t *ids_out) {
+    extern __shared__ uint2 lds_stack[];
+    uint2 *stk = lds_stack + threadIdx.x;
     if (ctl->overflow) return;   // a queue overflowed earlier in this frame: the frame is void
     const uint32_t n = min(ctl->n_rays[lp.level], lp.cap);
     ChunkWalk walk(n);
@@ -227,7 +258,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_intersect(DScene S, LevelParams lp
         if (active) {
             d3 o = mk3(q.ox[k], q.oy[k], q.oz[k]);
             d3 d = mk3(q.dx[k], q.dy[k], q.dz[k]);
-            Hit h = nearest_hit(S, o, d);
+            Hit h = nearest_hit<FAST>(S, F, stk, o, d);
             if (ids_out && lp.level == 0) ids_out[slot] = h.id;
             if (h.id == 0) {
                 // ray_tracer.py:65,72,132: misses keep the background colour
@@ -251,8 +282,43 @@ __global__ void __launch_bounds__(RT_BLOCK) k_intersect(DScene S, LevelParams lp
     }
 }
 
+// light-plane basis once per (hit, shadow light) (Light.py:252-260); k_shadow's 25 lanes of a segment reuse it
+__global__ void __launch_bounds__(RT_BLOCK) k_shadow_setup(DScene S, LevelParams lp, HitBuf hb, SegBuf sg, FrameCtl *ctl) {
+    if (ctl->overflow) return;
+    const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
+    const uint32_t nsl = (uint32_t)S.n_shadow_lights;
+    const uint64_t total = (uint64_t)n_hits * nsl;
+    ChunkWalk walk(total);
+    uint64_t first;
+    while (walk.next(first)) {
+        uint64_t seg = first + threadIdx.x;
+        if (seg >= total) continue;
+        uint32_t h = (uint32_t)(seg / nsl), ml = (uint32_t)(seg % nsl);
+        uint32_t r = hb.list[h];
+        int m = S.shadow_lights[ml];
+        d3 P = mk3(hb.px[r], hb.py[r], hb.pz[r]);
+        const DLight &Lt = S.lights[m];
+        d3 lpos = ld3(Lt.pos);
+        d3 dl = lpos - P;                              // Light.py:48-50
+        d3 L = dl / norm3(dl);
+        d3 up, right;
+        light_basis(neg3(L), up, right);               // Light.py:257
+        double radius = Lt.radius;
+        double gsz = radius / (double)lp.sh_rays;      // Light.py:254
+        double c0 = (radius - gsz) / 2;
+        d3 p00 = (lpos + c0 * up) - c0 * right;        // Light.py:260
+        sg.ux[seg] = up.x; sg.uy[seg] = up.y; sg.uz[seg] = up.z;
+        sg.rx[seg] = right.x; sg.ry[seg] = right.y; sg.rz[seg] = right.z;
+        sg.cx[seg] = p00.x; sg.cy[seg] = p00.y; sg.cz[seg] = p00.z;
+    }
+}
+
 // one lane per soft-shadow ray (Light.compute_shadows / get_shadow_rays, Light.py:178-288)
-__global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene S, LevelParams lp, RayQ q, HitBuf hb, FrameCtl *ctl) {
+template <bool FAST>
+__global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb, SegBuf sg,
+                                                     FrameCtl *ctl) {
+    extern __shared__ uint2 lds_stack[];
+    uint2 *stk = lds_stack + threadIdx.x;
     if (ctl->overflow) return;
     const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
     const uint32_t s = (uint32_t)lp.sh_rays, s2 = s * s;
@@ -272,16 +338,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene S, LevelParams lp, R
             uint32_t r = hb.list[h];
             int m = S.shadow_lights[ml];
             d3 P = mk3(hb.px[r], hb.py[r], hb.pz[r]);
-            const DLight &Lt = S.lights[m];
-            d3 lpos = ld3(Lt.pos);
-            d3 dl = lpos - P;                              // Light.py:48-50
-            d3 L = dl / norm3(dl);
-            d3 up, right;
-            light_basis(neg3(L), up, right);               // Light.py:257
-            double radius = Lt.radius;
-            double gsz = radius / (double)(int)s;          // Light.py:254
-            double c0 = (radius - gsz) / 2;
-            d3 p00 = (lpos + c0 * up) - c0 * right;        // Light.py:260
+            d3 up = mk3(sg.ux[seg], sg.uy[seg], sg.uz[seg]);
+            d3 right = mk3(sg.rx[seg], sg.ry[seg], sg.rz[seg]);
+            d3 p00 = mk3(sg.cx[seg], sg.cy[seg], sg.cz[seg]);
+            double gsz = S.lights[m].radius / (double)(int)s;          // Light.py:254
             d3 src = (p00 - ((double)b * gsz) * up) + ((double)a * gsz) * right;   // Light.py:273-274
             d3 u1 = mk3(0, 0, 0), u2 = mk3(0, 0, 0);
             if (lp.jitter) {
@@ -290,9 +350,24 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene S, LevelParams lp, R
             }
             src = src + (u1 * up + u2 * right);            // Light.py:277-279
             d3 vec = P - src;
-            d3 dir = vec / (norm3(vec) + RT_EPSILON);      // Light.py:283-286
-            Hit x = nearest_hit(S, src, dir);
-            lit = norm3(x.p - P) < RT_EPSILON;             // Light.py:219-221 (NaN -> unlit)
+            double nv = norm3(vec);
+            d3 dir = vec / (nv + RT_EPSILON);              // Light.py:283-286
+            bool done = false;
+            if (FAST && ray_is_tame(src, dir) && nv < 1e7) {
+                // P = src + (nv + 1e-6) * dir.  Nothing beyond P can be "the nearest hit within 1e-6 of P"
+                // unless it is the nearest hit overall, and then the ray is unlit either way; a confirmed hit
+                // closer than nv - 3e-6 makes the ray unlit whatever else lies on it.
+                float tP = __double2float_ru(nv + RT_EPSILON);
+                float tlim = fmaf(tP, RT_2M20, tP + 8e-6f);
+                FastState st;
+                fast_nearest<RT_BLOCK>(S, F, stk, src, dir, tlim, nv - 3e-6, st);
+                lit = !st.stop && (norm3(st.best.p - P) < RT_EPSILON);
+                done = true;
+            }
+            if (!done) {
+                Hit x = nearest_hit_exact(S, src, dir);
+                lit = norm3(x.p - P) < RT_EPSILON;         // Light.py:219-221 (NaN -> unlit)
+            }
         }
         // segmented popcount: consecutive lanes of one (hit, light) pair share a counter
         unsigned long long litmask = __ballot(lit);
@@ -453,10 +528,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_resolve(const double *fb, uint64_t
     }
 }
 
-__global__ void __launch_bounds__(RT_BLOCK) k_intersect_only(DScene S, const double *o, const double *d, uint64_t n,
-                                                             double *pts, int64_t *ids) {
+template <bool FAST>
+__global__ void __launch_bounds__(RT_BLOCK) k_intersect_only(DScene S, FastScene F, const double *o, const double *d,
+                                                             uint64_t n, double *pts, int64_t *ids) {
+    extern __shared__ uint2 lds_stack[];
+    uint2 *stk = lds_stack + threadIdx.x;
     for (uint64_t k = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x; k < n; k += (uint64_t)gridDim.x * RT_BLOCK) {
-        Hit h = nearest_hit(S, ld3(o + 3 * k), ld3(d + 3 * k));
+        Hit h = nearest_hit<FAST>(S, F, stk, ld3(o + 3 * k), ld3(d + 3 * k));
         pts[3 * k] = h.p.x; pts[3 * k + 1] = h.p.y; pts[3 * k + 2] = h.p.z;
         ids[k] = h.id;
     }
@@ -529,6 +607,9 @@ struct rt_ctx {
     std::string error;
     std::vector<void *> scene_allocs;
     DScene S{};
+    FastScene F{};
+    size_t lds_bytes = 0;   // per-lane traversal stacks: F.depth * RT_BLOCK * 8
+    SegBuf seg{};
     rt_scene_desc host{};   // scalar fields only (camera, settings)
     // frame buffers
     uint64_t cap = 0;       // ray-queue capacity
@@ -709,6 +790,77 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
     std::vector<int32_t> leaf(s->leaf_prim, s->leaf_prim + s->n_leaf_refs);
     TRY_C(upload(ctx, ctx->scene_allocs, leaf, &ctx->S.leaf_prim));
 
+    // ---- kd view of the same tree for the fast path (rt_fast.hpp) ----
+    {
+        std::vector<KNode> kn(nn);
+        std::vector<LeafF> lf((size_t)s->n_leaf_refs);
+        bool ok = true;
+        std::vector<int> depth(nn, 0);
+        int max_depth = 1;
+        for (int i = 0; i < nn && ok; ++i) {
+            const double *lo = s->node_lo + 3 * i, *hi = s->node_hi + 3 * i;
+            if (s->node_right[i] < 0) {
+                if ((unsigned)s->node_count[i] >= (1u << 30)) ok = false;
+                kn[i].a = (uint32_t)s->node_first[i];
+                kn[i].b = ((uint32_t)s->node_count[i] << 2) | 3u;
+                continue;
+            }
+            const int L = i + 1, R = s->node_right[i];
+            depth[L] = depth[R] = depth[i] + 1;
+            if (depth[i] + 2 > max_depth) max_depth = depth[i] + 2;
+            const double *llo = s->node_lo + 3 * L, *lhi = s->node_hi + 3 * L, *rlo = s->node_lo + 3 * R, *rhi = s->node_hi + 3 * R;
+            int axis = -1;
+            for (int k = 0; k < 3; ++k) if (lhi[k] != hi[k] || rlo[k] != lo[k]) { if (axis >= 0) ok = false; else axis = k; }
+            if (axis < 0) {   // degenerate split (cut == bound): both children equal the parent box
+                axis = 0;
+                double ext = hi[0] - lo[0];
+                for (int k = 1; k < 3; ++k) if (hi[k] - lo[k] > ext) { ext = hi[k] - lo[k]; axis = k; }
+            }
+            for (int k = 0; k < 3 && ok; ++k) {
+                if (llo[k] != lo[k] || rhi[k] != hi[k]) ok = false;               // children share the outer faces
+                if (k != axis && (lhi[k] != hi[k] || rlo[k] != lo[k])) ok = false;
+            }
+            const double cut = lhi[axis];
+            if (!(rlo[axis] == cut) || !(lo[axis] <= cut && cut <= hi[axis])) ok = false; // and tile the parent
+            const float cf = (float)cut;
+            memcpy(&kn[i].a, &cf, 4);
+            kn[i].b = ((uint32_t)R << 2) | (uint32_t)axis;
+        }
+        if (max_depth > 30) ok = false;   // per-lane stacks must fit the default 64 KB dynamic-LDS limit
+        for (int e = 0; e < s->n_leaf_refs; ++e) {
+            const int p = s->leaf_prim[e];
+            LeafF &f = lf[e];
+            memset(&f, 0, sizeof(f));
+            if (p < ns) {
+                const double *c = s->sph_center + 3 * p;
+                f.x = (float)c[0]; f.y = (float)c[1]; f.z = (float)c[2];
+                f.lx = (float)(c[0] - (double)f.x); f.ly = (float)(c[1] - (double)f.y); f.lz = (float)(c[2] - (double)f.z);
+                f.r = round_up(fabs(s->sph_radius[p]));
+                f.pk = ((uint32_t)p << 2) | 1u;
+                if (!(s->sph_r2[p] <= (double)f.r * (double)f.r * 1.0000001)) ok = false;   // r2 must be radius**2
+            } else {
+                const double *blo = s->box_lo + 3 * (p - ns), *bhi = s->box_hi + 3 * (p - ns);
+                f.x = round_down(blo[0]); f.y = round_down(blo[1]); f.z = round_down(blo[2]);
+                f.lx = round_up(bhi[0]); f.ly = round_up(bhi[1]); f.lz = round_up(bhi[2]);
+                f.pk = ((uint32_t)p << 2) | 2u;
+            }
+        }
+        if ((size_t)ns + nb >= (1u << 30)) ok = false;
+        TRY_C(upload(ctx, ctx->scene_allocs, kn, &ctx->F.knodes));
+        TRY_C(upload(ctx, ctx->scene_allocs, lf, &ctx->F.leaves));
+        float ext = 0;
+        for (int k = 0; k < 3; ++k) {
+            ctx->F.root_lo[k] = round_down(s->node_lo[k]);
+            ctx->F.root_hi[k] = round_up(s->node_hi[k]);
+            ext = fmaxf(ext, fmaxf(fabsf(ctx->F.root_lo[k]), fabsf(ctx->F.root_hi[k])));
+        }
+        ctx->F.extent = ext * 1.000001f;
+        ctx->F.depth = max_depth;
+        ctx->F.ok = ok ? 1 : 0;
+        ctx->lds_bytes = ok ? (size_t)max_depth * RT_BLOCK * sizeof(uint2) : 0;
+        if (getenv("RT_AMD_DEBUG")) fprintf(stderr, "[rt_amd] kd view: ok=%d depth=%d lds=%zu B\n", ctx->F.ok, max_depth, ctx->lds_bytes);
+    }
+
     // ---- planes / surfaces / materials / lights ----
     std::vector<DPlane> planes(s->n_planes);
     for (int i = 0; i < s->n_planes; ++i) {
@@ -814,6 +966,10 @@ static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
     uint64_t nlit = cap * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1);
     TRY_A(dalloc(ctx, &hb.lit, nlit));
     HIP_TRY(ctx, hipMemsetAsync(hb.lit, 0, nlit * sizeof(uint32_t), ctx->stream));
+    SegBuf &sg = ctx->seg;
+    TRY_A(dalloc(ctx, &sg.ux, nlit)); TRY_A(dalloc(ctx, &sg.uy, nlit)); TRY_A(dalloc(ctx, &sg.uz, nlit));
+    TRY_A(dalloc(ctx, &sg.rx, nlit)); TRY_A(dalloc(ctx, &sg.ry, nlit)); TRY_A(dalloc(ctx, &sg.rz, nlit));
+    TRY_A(dalloc(ctx, &sg.cx, nlit)); TRY_A(dalloc(ctx, &sg.cy, nlit)); TRY_A(dalloc(ctx, &sg.cz, nlit));
     TRY_A(dalloc(ctx, &ctx->fb, slots * 3));
 #undef TRY_A
     ctx->cap = cap;
@@ -899,17 +1055,22 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
     lp.sh_rays = sh; lp.jitter = p->jitter; lp.seed = p->seed; lp.cap = (uint32_t)ctx->cap; lp.flags = p->flags;
     dim3 grid(ctx->grid), block(RT_BLOCK);
     const bool prof = (p->flags & RT_FLAG_PROFILE) != 0;
+    const bool fast = ctx->F.ok && !(p->flags & RT_FLAG_EXACT_TRAVERSAL);
     for (int level = 0; level <= rec; ++level) {
         lp.level = level;
         lp.last_level = (level == rec) ? 1 : 0;
         RayQ &qc = ctx->q[level & 1], &qn = ctx->q[(level + 1) & 1];
         const int e = 2 + 6 * level;
         PROF_MARK(e + 0);
-        hipLaunchKernelGGL(k_intersect, grid, block, 0, st, ctx->S, lp, qc, ctx->hb, ctx->ctl, ctx->fb, d_ids);
+        if (fast) hipLaunchKernelGGL(k_intersect<true>, grid, block, ctx->lds_bytes, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->ctl, ctx->fb, d_ids);
+        else hipLaunchKernelGGL(k_intersect<false>, grid, block, 0, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->ctl, ctx->fb, d_ids);
         PROF_MARK(e + 1);
         PROF_MARK(e + 2);
-        if (ctx->S.n_shadow_lights > 0)
-            hipLaunchKernelGGL(k_shadow, grid, block, 0, st, ctx->S, lp, qc, ctx->hb, ctx->ctl);
+        if (ctx->S.n_shadow_lights > 0) {
+            hipLaunchKernelGGL(k_shadow_setup, grid, block, 0, st, ctx->S, lp, ctx->hb, ctx->seg, ctx->ctl);
+            if (fast) hipLaunchKernelGGL(k_shadow<true>, grid, block, ctx->lds_bytes, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->seg, ctx->ctl);
+            else hipLaunchKernelGGL(k_shadow<false>, grid, block, 0, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->seg, ctx->ctl);
+        }
         PROF_MARK(e + 3);
         PROF_MARK(e + 4);
         hipLaunchKernelGGL(k_shade, grid, block, 0, st, ctx->S, lp, qc, qn, ctx->hb, ctx->ctl, ctx->fb);
@@ -1132,7 +1293,10 @@ extern "C" int rt_intersect(rt_ctx *ctx, const double *origins, const double *di
     TRY_I(hipMalloc((void **)&d_i, (size_t)n * sizeof(int64_t)));
     TRY_I(hipMemcpy(d_o, origins, vb, hipMemcpyHostToDevice));
     TRY_I(hipMemcpy(d_d, directions, vb, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_intersect_only, dim3(ctx->grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->S, d_o, d_d, (uint64_t)n, d_p, d_i);
+    if (ctx->F.ok && !getenv("RT_AMD_EXACT"))
+        hipLaunchKernelGGL(k_intersect_only<true>, dim3(ctx->grid), dim3(RT_BLOCK), ctx->lds_bytes, ctx->stream, ctx->S, ctx->F, d_o, d_d, (uint64_t)n, d_p, d_i);
+    else
+        hipLaunchKernelGGL(k_intersect_only<false>, dim3(ctx->grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->S, ctx->F, d_o, d_d, (uint64_t)n, d_p, d_i);
     TRY_I(hipGetLastError());
     TRY_I(hipStreamSynchronize(ctx->stream));
     TRY_I(hipMemcpy(points_out, d_p, vb, hipMemcpyDeviceToHost));

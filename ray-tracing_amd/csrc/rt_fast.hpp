@@ -1,0 +1,241 @@
+// rt_fast.hpp - the fast nearest-hit query: float32 conservative culling + float64 decisions.
+//
+// The reference's query (BSPNode.py:123-210) is, per ray, "argmin over all primitives of every
+// leaf whose box the ray enters of the Euclidean hit distance, first in DFS order wins exact
+// ties".  Because the tree is a spatial-median kd-tree whose child boxes tile their parent
+// (BSPNode.py:71-94), that result equals the nearest hit over ALL primitives (BSP ==
+// brute force), so any traversal that (a) never skips a leaf holding a hit that could be nearest
+// and (b) resolves exact distance ties the way the reference's visiting order does, returns the
+// same answer.  This file does:
+//
+//   * kd traversal, near child first, one split plane per node (8-byte nodes), per-lane stack in
+//     LDS ([level][lane] columns of 8-byte entries: conflict-free ds_read/write_b64);
+//   * all culling in float32 with explicit error margins (a cull may only say "cannot matter");
+//   * leaf entries carry a 32-byte float32 record (sphere centre as hi+lo float pair, so the
+//     centre-origin difference has no cancellation error; box bounds rounded outward);
+//   * every primitive that survives the float32 reject is decided by the float64 functions of
+//     rt_device.hpp (reference operation order), and distances are compared in float64;
+//   * an exact tie between two DIFFERENT primitives (coincident surfaces) raises `tie`; the caller
+//     then re-runs the reference-order walk (nearest_hit_exact) for that ray - rare, exact.
+//
+// Shadow rays additionally stop at the shaded point: the lit test of Light.py:219-221 only asks
+// whether the nearest hit lies within 1e-6 of P, so nodes entirely beyond P are skipped and the
+// query ends as soon as one float64-confirmed hit is closer than |P-src| - 3e-6.
+#pragma once
+#include "rt_device.hpp"
+
+struct KNode {      // 8 B.  internal: a = float bits of the cut, b = (right child << 2) | axis
+    uint32_t a;     //       leaf:     a = first leaf entry,     b = (count << 2) | 3
+    uint32_t b;
+};
+struct LeafF {      // 32 B, one per leaf entry, in leaf-list order
+    float x, y, z;  // sphere: centre (float part)            box: lo rounded down
+    float r;        // sphere: radius rounded up
+    float lx, ly, lz;  // sphere: centre - (double)float part  box: hi rounded up
+    uint32_t pk;    // (primitive number << 2) | kind (1 sphere, 2 box)
+};
+
+#define RT_2M18 3.8146973e-06f
+#define RT_2M19 1.9073486e-06f
+#define RT_2M20 9.5367432e-07f
+#define RT_2M38 3.6379788e-12f
+
+struct FastScene {
+    const KNode *knodes;
+    const LeafF *leaves;
+    float root_lo[3], root_hi[3];   // rounded outward
+    float extent;                   // max |coordinate| of the root box, rounded up
+    int32_t depth;                  // tree depth = stack entries needed per lane
+    int32_t ok;                     // 0: tree is not an exact kd tiling (or too deep) -> use the exact walk
+};
+
+struct FastState {
+    Hit best;
+    bool tie;
+    bool stop;       // shadow early-out taken
+    float tbest;     // float32 upper bound of the best hit's ray parameter
+};
+
+// candidate confirmed in float64: strict-< update on the Euclidean distance recomputed from the
+// hit point (ray_functions.py:61-77); the far clip of Background (Background.py:23) is applied
+// lazily - only hits farther than 1e8 can lose against it.
+__device__ __forceinline__ void fast_consider(const DScene &S, FastState &st, d3 o, d3 d, double t, int32_t id,
+                                              double early_dist) {
+    d3 p = o + t * d;
+    if (nan3_any(p)) return;
+    double dist = norm3(p - o);
+    if (dist >= RT_MAX_RENDER_DISTANCE && S.far_clip) {
+        double far = norm3(mk3(RT_MAX_RENDER_DISTANCE, RT_MAX_RENDER_DISTANCE, RT_MAX_RENDER_DISTANCE) - o);
+        if (!(dist < far)) return;
+    }
+    if (dist < st.best.dist) {
+        st.best.p = p;
+        st.best.dist = dist;
+        st.best.id = id;
+        st.tie = false;
+        float tf = __double2float_ru(t);
+        st.tbest = fmaf(fabsf(tf), RT_2M20, tf);
+        if (dist < early_dist) st.stop = true;
+    } else if (dist == st.best.dist && id != st.best.id) {
+        st.tie = true;
+    }
+}
+
+// o, d: the float64 ray.  tlim: float32 upper bound of the ray parameters that can matter
+// (+inf for ordinary rays).  early_dist: stop as soon as a confirmed hit is closer than this
+// (-inf for ordinary rays).  stk: this lane's LDS stack column (stride RT_STACK_STRIDE entries).
+template <int STRIDE>
+__device__ __forceinline__ void fast_nearest(const DScene &S, const FastScene &F, uint2 *stk, d3 o, d3 d, float tlim,
+                                             double early_dist, FastState &st) {
+    st.best.p = mk3(dnan(), dnan(), dnan());
+    st.best.dist = dinf();
+    st.best.id = 0;
+    st.tie = false;
+    st.stop = false;
+    st.tbest = tlim;
+
+    const float of0 = (float)o.x, of1 = (float)o.y, of2 = (float)o.z;
+    const float ol0 = (float)(o.x - (double)of0), ol1 = (float)(o.y - (double)of1), ol2 = (float)(o.z - (double)of2);
+    const float df0 = (float)d.x, df1 = (float)d.y, df2 = (float)d.z;
+    // reciprocal clamped to +-1e30: a zero (or float-underflowed) direction component behaves like a ray
+    // parallel to that axis, and every product below stays finite or overflows to a harmless +-inf
+    const float in0 = fminf(fmaxf(1.0f / df0, -1e30f), 1e30f);
+    const float in1 = fminf(fmaxf(1.0f / df1, -1e30f), 1e30f);
+    const float in2 = fminf(fmaxf(1.0f / df2, -1e30f), 1e30f);
+    const float K = fmaxf(fmaxf(fabsf(of0), fabsf(of1)), fmaxf(fabsf(of2), F.extent));
+    const float Eabs = K * RT_2M19;
+    const float E0 = Eabs * fabsf(in0), E1 = Eabs * fabsf(in1), E2 = Eabs * fabsf(in2);
+    const float Emax = fmaxf(E0, fmaxf(E1, E2));
+    const float af = fmaf(df0, df0, fmaf(df1, df1, df2 * df2));                 // |d|^2 (float32)
+    const float dnf = sqrtf(af) * 1.000001f;                                    // |d| rounded up
+
+    // ---- planes (root list, few, wave-uniform): float32 reject, float64 decision -------------
+    for (int k = 0; k < S.n_planes; ++k) {
+        const DPlane &pl = S.planes[k];
+        const float n0 = (float)pl.n[0], n1 = (float)pl.n[1], n2 = (float)pl.n[2];
+        float vn = fmaf(df0, n0, fmaf(df1, n1, df2 * n2));
+        float evn = RT_2M20 * (fabsf(df0 * n0) + fabsf(df1 * n1) + fabsf(df2 * n2));
+        if (vn > evn) continue;                                   // certainly facing away: one-sided planes miss
+        if (st.tbest < __int_as_float(0x7f800000) && vn < -evn) { // segment end known: is the plane beyond it?
+            float num = -(fmaf(of0, n0, fmaf(of1, n1, of2 * n2)) + (float)pl.d);
+            float enum_ = RT_2M19 * (fabsf(of0 * n0) + fabsf(of1 * n1) + fabsf(of2 * n2) + fabsf((float)pl.d)) + RT_2M19 * K;
+            // t = num / vn with vn < 0: t > tbest  <=>  num < tbest * vn  (both sides bounded conservatively)
+            float rhs = st.tbest * (vn - evn) * 1.000002f;         // more negative than tbest*vn
+            if (num + enum_ < rhs) continue;                       // certainly beyond the segment
+        }
+        double t;
+        if (plane_exact(o, d, pl, t)) fast_consider(S, st, o, d, t, pl.id, early_dist);
+        if (st.stop) return;
+    }
+
+    // ---- root interval (float32, conservative) ------------------------------------------------
+    float tmin, tmax;
+    {
+        float a0 = (F.root_lo[0] - of0) * in0, b0 = (F.root_hi[0] - of0) * in0;
+        float a1 = (F.root_lo[1] - of1) * in1, b1 = (F.root_hi[1] - of1) * in1;
+        float a2 = (F.root_lo[2] - of2) * in2, b2 = (F.root_hi[2] - of2) * in2;
+        float n0 = fminf(a0, b0), x0 = fmaxf(a0, b0);
+        float n1 = fminf(a1, b1), x1 = fmaxf(a1, b1);
+        float n2 = fminf(a2, b2), x2 = fmaxf(a2, b2);
+        n0 -= fmaf(fabsf(n0), RT_2M20, E0); x0 += fmaf(fabsf(x0), RT_2M20, E0);
+        n1 -= fmaf(fabsf(n1), RT_2M20, E1); x1 += fmaf(fabsf(x1), RT_2M20, E1);
+        n2 -= fmaf(fabsf(n2), RT_2M20, E2); x2 += fmaf(fabsf(x2), RT_2M20, E2);
+        tmin = fmaxf(fmaxf(n0, n1), fmaxf(n2, 0.0f));
+        tmax = fminf(fminf(x0, x1), fminf(x2, st.tbest));
+    }
+    if (tmin > tmax) return;
+
+    uint32_t node = 0;
+    int sp = 0;
+    for (;;) {
+        KNode nd = F.knodes[node];
+        // ---- descend to a leaf, near child first ----
+        while ((nd.b & 3u) != 3u) {
+            const uint32_t ax = nd.b & 3u;
+            const float cut = __uint_as_float(nd.a);
+            const float oa = ax == 0 ? of0 : (ax == 1 ? of1 : of2);
+            const float ia = ax == 0 ? in0 : (ax == 1 ? in1 : in2);
+            const float ea = ax == 0 ? E0 : (ax == 1 ? E1 : E2);
+            const float t = (cut - oa) * ia;
+            const float m = fmaf(fabsf(t), RT_2M20, ea);
+            const float tl = t - m, th = t + m;
+            const uint32_t left = node + 1, right = nd.b >> 2;
+            const bool dneg = ia < 0.0f;      // side the ray comes from, consistent with the sign used for t
+            const uint32_t nearc = dneg ? right : left, farc = dneg ? left : right;
+            if (tl > tmax) node = nearc;                 // plane beyond the segment: near side only
+            else if (th < tmin) node = farc;             // plane before the segment: far side only
+            else {                                       // both (NaN lands here too): far side waits on the stack
+                stk[sp * STRIDE] = make_uint2(farc, __float_as_uint(tmax));
+                ++sp;
+                node = nearc;
+                tmax = fminf(tmax, th);
+            }
+            nd = F.knodes[node];
+        }
+        // ---- leaf ----
+        {
+            const uint32_t first = nd.a, cnt = nd.b >> 2;
+            for (uint32_t e = first; e < first + cnt; ++e) {
+                const LeafF lf = F.leaves[e];
+                const uint32_t kind = lf.pk & 3u, prim = lf.pk >> 2;
+                const float tcur = st.tbest;
+                bool cand;
+                if (kind == 1u) {
+                    const float px = (lf.x - of0) + (lf.lx - ol0);
+                    const float py = (lf.y - of1) + (lf.ly - ol1);
+                    const float pz = (lf.z - of2) + (lf.lz - ol2);
+                    const float b = fmaf(px, df0, fmaf(py, df1, pz * df2));
+                    const float pp = fmaf(px, px, fmaf(py, py, pz * pz));
+                    const float r2 = lf.r * lf.r;
+                    const float disc = fmaf(b, b, -af * (pp - r2));
+                    const float ed = af * (RT_2M18 * (pp + r2));
+                    cand = !(disc < -ed);
+                    // both roots certainly behind the origin
+                    if ((b < 0.0f) && (b * b > RT_2M38 * pp * af) && (pp - r2 > RT_2M19 * (pp + r2))) cand = false;
+                    // sphere certainly beyond the part of the ray that can matter
+                    const float far = fmaf(tcur, dnf, lf.r);
+                    if (pp > far * far * 1.00001f) cand = false;
+                } else {
+                    float a0 = (lf.x - of0) * in0, b0 = (lf.lx - of0) * in0;
+                    float a1 = (lf.y - of1) * in1, b1 = (lf.ly - of1) * in1;
+                    float a2 = (lf.z - of2) * in2, b2 = (lf.lz - of2) * in2;
+                    float n0 = fminf(a0, b0), x0 = fmaxf(a0, b0);
+                    float n1 = fminf(a1, b1), x1 = fmaxf(a1, b1);
+                    float n2 = fminf(a2, b2), x2 = fmaxf(a2, b2);
+                    n0 -= fmaf(fabsf(n0), RT_2M20, E0); x0 += fmaf(fabsf(x0), RT_2M20, E0);
+                    n1 -= fmaf(fabsf(n1), RT_2M20, E1); x1 += fmaf(fabsf(x1), RT_2M20, E1);
+                    n2 -= fmaf(fabsf(n2), RT_2M20, E2); x2 += fmaf(fabsf(x2), RT_2M20, E2);
+                    const float tn = fmaxf(fmaxf(n0, n1), n2), tf = fminf(fminf(x0, x1), x2);
+                    cand = !(tn > tf) && !(tf < 0.0f) && !(tn > tcur);
+                }
+                if (cand) {
+                    const DPrim *pr = S.prims + prim;
+                    double t;
+                    if (kind == 1u) {
+                        if (sphere_exact(o, d, dot3(d, d), pr->a, pr->b[0], t)) fast_consider(S, st, o, d, t, pr->id, early_dist);
+                    } else {
+                        d3 inv = mk3(d.x != 0 ? 1.0 / d.x : dinf(), d.y != 0 ? 1.0 / d.y : dinf(), d.z != 0 ? 1.0 / d.z : dinf());
+                        if (slab_exact(o, inv, pr->a, pr->b, true, t)) fast_consider(S, st, o, d, t, pr->id, early_dist);
+                    }
+                    if (st.stop) return;
+                }
+            }
+        }
+        // ---- next pending far node: it starts where the leaf just visited ended ----
+        if (sp == 0) return;
+        float prev = tmax;
+        tmin = fmaxf(prev - fmaf(fabsf(prev), RT_2M19, 2.0f * Emax), 0.0f);
+        if (tmin > st.tbest) return;                     // everything still pending is farther than the best hit
+        --sp;
+        const uint2 top = stk[sp * STRIDE];
+        node = top.x;
+        tmax = fminf(__uint_as_float(top.y), st.tbest);
+        while (tmin > tmax) {                            // entry emptied by a better hit found meanwhile
+            if (sp == 0) return;
+            --sp;
+            const uint2 t2 = stk[sp * STRIDE];
+            node = t2.x;
+            tmax = fminf(__uint_as_float(t2.y), st.tbest);
+        }
+    }
+}

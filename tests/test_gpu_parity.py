@@ -181,3 +181,38 @@ def test_bad_arguments_are_reported(gpu_ctx):
         ctx.render(abi.render_params(8, 8, sh_rays=0))
     with pytest.raises(ValueError):
         ctx.intersect(np.zeros((4, 3)), np.zeros((5, 3)))
+
+
+# ------------------------------------------------------------------ fast path == exact walk
+@pytest.mark.parametrize("tag,w,h,sh,rec", [("small", 160, 100, 3, 5), ("original", 200, 200, 2, 10),
+                                            ("pool", 320, 180, 5, 10), ("synth400", 320, 180, 5, 5)])
+def test_fast_traversal_equals_reference_order_walk(gpu_ctx, tag, w, h, sh, rec):
+    """float32-culled kd traversal (default) against the float64 reference-order walk
+    (RT_FLAG_EXACT_TRAVERSAL): ids, ray counts and the float32 image must be identical."""
+    ctx = gpu_ctx(tag)
+    fast = ctx.render(abi.render_params(w, h, sh_rays=sh, rec_max=rec, jitter=True, seed=42))
+    exact = ctx.render(abi.render_params(w, h, sh_rays=sh, rec_max=rec, jitter=True, seed=42,
+                                         flags=abi.RT_FLAG_EXACT_TRAVERSAL))
+    assert np.array_equal(fast["ids"], exact["ids"])
+    assert fast["stats"]["rays"] == exact["stats"]["rays"]
+    assert np.array_equal(fast["rgb8"], exact["rgb8"])
+    assert np.abs(fast["rgb"] - exact["rgb"]).max() < 1e-6
+
+
+def test_fast_intersect_axis_parallel_and_degenerate_rays(gpu_ctx, oracle):
+    """Rays with zero direction components, origins on split planes and inside primitives."""
+    sc = load_scene("small")
+    f = sc["bsp"].flat
+    rng = np.random.default_rng(1)
+    n = 3000
+    o = rng.uniform(f.lo[0] - 1, f.hi[0] + 1, (n, 3))
+    d = np.zeros((n, 3))
+    d[np.arange(n), rng.integers(0, 3, n)] = rng.choice([-1.0, 1.0], n)      # axis parallel
+    d[::3] += rng.normal(size=(len(d[::3]), 3)) * 1e-3                          # nearly axis parallel
+    cuts = f.hi[1:40, :]                                                        # origins exactly on node planes
+    o[:117:3] = cuts.reshape(-1, 3)[:39]
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    pts, ids = gpu_ctx("small").intersect(o, d)
+    opts, oids, _ = oracle.intersect(sc["packed"], o, d)
+    assert np.array_equal(ids, oids)
+    assert np.array_equal(pts, opts, equal_nan=True)
