@@ -135,6 +135,8 @@ typedef struct rt_render_params {
 
 #define RT_FLAG_EXACT_TRAVERSAL 1  /* diagnostic: visit nodes with the reference's float64 slab test only
                                       (no float32 culling, no pruning); results must be identical */
+#define RT_FLAG_NO_BEAM 4          /* diagnostic: decide every shadow ray with its own float64-confirmed traversal
+                                      instead of the per-(hit,light) beam + float32 filtered predicates */
 #define RT_FLAG_PROFILE 2          /* bracket every kernel launch with HIP events on the launch stream and
                                       report per-family device time in rt_stats (used by bench.py's roofline) */
 

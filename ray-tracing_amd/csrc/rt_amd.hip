@@ -28,6 +28,7 @@
 #include "../../include/rt_amd.h"
 #include "rt_device.hpp"
 #include "rt_fast.hpp"
+#include "rt_shadow.hpp"
 
 #define RT_BLOCK 256
 #define RT_MAX_LEVELS 64
@@ -282,8 +283,12 @@ __global__ void __launch_bounds__(RT_BLOCK) k_intersect(DScene S, FastScene F, L
     }
 }
 
-// light-plane basis once per (hit, shadow light) (Light.py:252-260); k_shadow's 25 lanes of a segment reuse it
-__global__ void __launch_bounds__(RT_BLOCK) k_shadow_setup(DScene S, LevelParams lp, HitBuf hb, SegBuf sg, FrameCtl *ctl) {
+// light-plane basis once per (hit, shadow light) (Light.py:252-260); the s*s lanes of a segment reuse it.
+// BEAM: additionally the float32 header and the candidate list of the filtered path (rt_shadow.hpp).
+template <bool BEAM>
+__global__ void __launch_bounds__(RT_BLOCK) k_shadow_setup(DScene S, FastScene F, LevelParams lp, HitBuf hb, SegBuf sg,
+                                                           BeamBuf bb, FrameCtl *ctl) {
+    extern __shared__ uint2 lds_stack[];
     if (ctl->overflow) return;
     const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
     const uint32_t nsl = (uint32_t)S.n_shadow_lights;
@@ -310,15 +315,118 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_setup(DScene S, LevelParams
         sg.ux[seg] = up.x; sg.uy[seg] = up.y; sg.uz[seg] = up.z;
         sg.rx[seg] = right.x; sg.ry[seg] = right.y; sg.rz[seg] = right.z;
         sg.cx[seg] = p00.x; sg.cy[seg] = p00.y; sg.cz[seg] = p00.z;
+        if (BEAM) {
+            SegF hd;
+            d3 q0 = p00 - P;
+            hd.q0[0] = (float)q0.x; hd.q0[1] = (float)q0.y; hd.q0[2] = (float)q0.z;
+            hd.g = (float)gsz;
+            hd.up[0] = (float)up.x; hd.up[1] = (float)up.y; hd.up[2] = (float)up.z;
+            hd.right[0] = (float)right.x; hd.right[1] = (float)right.y; hd.right[2] = (float)right.z;
+            hd.pad = 0.0f;
+            for (int k = 0; k < RT_PMAX; ++k) hd.pd[k] = 0.0f;
+            for (int k = 0; k < S.n_planes && k < RT_PMAX; ++k) {
+                const DPlane &pl = S.planes[k];
+                hd.pd[k] = (float)(dot3(ld3(pl.n), P) + pl.d);
+            }
+            // box of every sample origin of the pair, relative to P: grid points a,b in [0,s-1] and the
+            // component-wise deviations of Light.py:277-279 (|u| <= g on each of up and right)
+            const float sm1 = (float)(lp.sh_rays - 1);
+            float cB[3], hh[3];
+            for (int k = 0; k < 3; ++k) {
+                cB[k] = hd.q0[k] + 0.5f * sm1 * hd.g * (hd.right[k] - hd.up[k]);
+                hh[k] = (0.5f * sm1 + 1.0f) * hd.g * (fabsf(hd.up[k]) + fabsf(hd.right[k]));
+                hh[k] = fmaf(RT_2M19, fabsf(cB[k]) + hh[k], hh[k]) + 1e-6f;
+            }
+            bool tame = ray_is_tame(P, L) && fabs(q0.x) < 1e7 && fabs(q0.y) < 1e7 && fabs(q0.z) < 1e7;
+            BeamStack bs;
+            bs.a = lds_stack + threadIdx.x;
+            bs.b = (float *)(lds_stack + (size_t)F.depth * RT_BLOCK) + threadIdx.x;
+            hd.ncand = tame ? beam_collect<RT_BLOCK>(S, F, bs, P, cB, hh, bb.cand + seg * RT_CMAX) : RT_CMAX + 1;
+            bb.seg[seg] = hd;
+        }
     }
 }
 
-// one lane per soft-shadow ray (Light.compute_shadows / get_shadow_rays, Light.py:178-288)
+// float64-confirmed verdict for shadow ray g (rt_fast.hpp), or the reference-order walk when !FAST
+template <bool FAST>
+__device__ __forceinline__ bool shadow_ray_lit(const DScene &S, const FastScene &F, uint2 *stk, const LevelParams &lp,
+                                               const RayQ &q, const HitBuf &hb, const SegBuf &sg, uint64_t g) {
+    const uint32_t s = (uint32_t)lp.sh_rays, s2 = s * s;
+    const uint32_t nsl = (uint32_t)S.n_shadow_lights;
+    const uint64_t seg = g / s2;
+    uint32_t h = (uint32_t)(seg / nsl), ml = (uint32_t)(seg % nsl), kk = (uint32_t)(g % s2);
+    uint32_t a = kk / s, b = kk % s;
+    uint32_t r = hb.list[h];
+    int m = S.shadow_lights[ml];
+    d3 P = mk3(hb.px[r], hb.py[r], hb.pz[r]);
+    d3 up = mk3(sg.ux[seg], sg.uy[seg], sg.uz[seg]);
+    d3 right = mk3(sg.rx[seg], sg.ry[seg], sg.rz[seg]);
+    d3 p00 = mk3(sg.cx[seg], sg.cy[seg], sg.cz[seg]);
+    double gsz = S.lights[m].radius / (double)(int)s;          // Light.py:254
+    d3 src = (p00 - ((double)b * gsz) * up) + ((double)a * gsz) * right;   // Light.py:273-274
+    d3 u1 = mk3(0, 0, 0), u2 = mk3(0, 0, 0);
+    if (lp.jitter) {
+        u1 = jitter3(lp.seed, q.gpix[r], q.path[r], (uint32_t)m, kk, 0u, gsz);
+        u2 = jitter3(lp.seed, q.gpix[r], q.path[r], (uint32_t)m, kk, 1u, gsz);
+    }
+    src = src + (u1 * up + u2 * right);            // Light.py:277-279
+    d3 vec = P - src;
+    double nv = norm3(vec);
+    d3 dir = vec / (nv + RT_EPSILON);              // Light.py:283-286
+    if (FAST && ray_is_tame(src, dir) && nv < 1e7) {
+        // P = src + (nv + 1e-6) * dir.  Nothing beyond P can be "the nearest hit within 1e-6 of P"
+        // unless it is the nearest hit overall, and then the ray is unlit either way; a confirmed hit
+        // closer than nv - 3e-6 makes the ray unlit whatever else lies on it.
+        float tP = __double2float_ru(nv + RT_EPSILON);
+        float tlim = fmaf(tP, RT_2M20, tP + 8e-6f);
+        FastState st;
+        fast_nearest<RT_BLOCK>(S, F, stk, src, dir, tlim, nv - 3e-6, st);
+        return !st.stop && (norm3(st.best.p - P) < RT_EPSILON);
+    }
+    Hit x = nearest_hit_exact(S, src, dir);
+    return norm3(x.p - P) < RT_EPSILON;            // Light.py:219-221 (NaN -> unlit)
+}
+
+// segmented popcount: consecutive lanes of one (hit, light) pair share a counter, one atomic per segment
+__device__ __forceinline__ void add_lit_counts(uint32_t *lit_ctr, bool active, bool lit, uint64_t seg, int lane) {
+    unsigned long long litmask = __ballot(lit);
+    uint64_t prev = __shfl_up(seg, 1);
+    bool leader = active && (lane == 0 || prev != seg);
+    unsigned long long leaders = __ballot(leader);
+    if (leader) {
+        unsigned long long above = (lane == 63) ? 0ull : (leaders >> (lane + 1));
+        int next = above ? (lane + 1 + (__ffsll((long long)above) - 1)) : 64;
+        unsigned long long segmask = (next == 64 ? ~0ull : ((1ull << next) - 1ull)) & ~((1ull << lane) - 1ull);
+        uint32_t cnt = (uint32_t)__popcll(litmask & segmask);
+        if (cnt) atomicAdd(&lit_ctr[seg], cnt);
+    }
+}
+
+// one lane per soft-shadow ray, every ray decided in float64 (Light.compute_shadows, Light.py:178-288)
 template <bool FAST>
 __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb, SegBuf sg,
                                                      FrameCtl *ctl) {
     extern __shared__ uint2 lds_stack[];
     uint2 *stk = lds_stack + threadIdx.x;
+    if (ctl->overflow) return;
+    const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
+    const uint32_t s2 = (uint32_t)(lp.sh_rays * lp.sh_rays);
+    const uint64_t total = (uint64_t)n_hits * (uint32_t)S.n_shadow_lights * s2;
+    ChunkWalk walk(total);
+    uint64_t first;
+    const int lane = threadIdx.x & 63;
+    while (walk.next(first)) {
+        uint64_t g = first + threadIdx.x;
+        bool active = g < total;
+        uint64_t seg = active ? g / s2 : ~0ull;       // (hit, light) pair: h * nsl + ml
+        bool lit = active && shadow_ray_lit<FAST>(S, F, stk, lp, q, hb, sg, g);
+        add_lit_counts(hb.lit, active, lit, seg, lane);
+    }
+}
+
+// one lane per soft-shadow ray, float32 filtered predicates on the pair's candidate list (rt_shadow.hpp);
+// undecided rays go to the queue
+__global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams lp, RayQ q, HitBuf hb, BeamBuf bb, FrameCtl *ctl) {
     if (ctl->overflow) return;
     const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
     const uint32_t s = (uint32_t)lp.sh_rays, s2 = s * s;
@@ -328,59 +436,99 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene S, FastScene F, Leve
     uint64_t first;
     const int lane = threadIdx.x & 63;
     while (walk.next(first)) {
-        uint64_t g = first + threadIdx.x;
+        // first is a multiple of RT_BLOCK: split it once per chunk (uniform), then 32-bit arithmetic per lane
+        const uint64_t seg0 = first / s2;
+        const uint32_t rem0 = (uint32_t)(first % s2);
+        const uint32_t off = rem0 + threadIdx.x;
+        const uint64_t g = first + threadIdx.x;
         bool active = g < total;
-        bool lit = false;
-        uint64_t seg = active ? g / s2 : ~0ull;       // (hit, light) pair: h * nsl + ml
+        const uint64_t seg = active ? seg0 + off / s2 : ~0ull;
+        bool lit = false, unsure = false;
         if (active) {
-            uint32_t h = (uint32_t)(seg / nsl), ml = (uint32_t)(seg % nsl), kk = (uint32_t)(g % s2);
-            uint32_t a = kk / s, b = kk % s;
-            uint32_t r = hb.list[h];
-            int m = S.shadow_lights[ml];
-            d3 P = mk3(hb.px[r], hb.py[r], hb.pz[r]);
-            d3 up = mk3(sg.ux[seg], sg.uy[seg], sg.uz[seg]);
-            d3 right = mk3(sg.rx[seg], sg.ry[seg], sg.rz[seg]);
-            d3 p00 = mk3(sg.cx[seg], sg.cy[seg], sg.cz[seg]);
-            double gsz = S.lights[m].radius / (double)(int)s;          // Light.py:254
-            d3 src = (p00 - ((double)b * gsz) * up) + ((double)a * gsz) * right;   // Light.py:273-274
-            d3 u1 = mk3(0, 0, 0), u2 = mk3(0, 0, 0);
-            if (lp.jitter) {
-                u1 = jitter3(lp.seed, q.gpix[r], q.path[r], (uint32_t)m, kk, 0u, gsz);
-                u2 = jitter3(lp.seed, q.gpix[r], q.path[r], (uint32_t)m, kk, 1u, gsz);
-            }
-            src = src + (u1 * up + u2 * right);            // Light.py:277-279
-            d3 vec = P - src;
-            double nv = norm3(vec);
-            d3 dir = vec / (nv + RT_EPSILON);              // Light.py:283-286
-            bool done = false;
-            if (FAST && ray_is_tame(src, dir) && nv < 1e7) {
-                // P = src + (nv + 1e-6) * dir.  Nothing beyond P can be "the nearest hit within 1e-6 of P"
-                // unless it is the nearest hit overall, and then the ray is unlit either way; a confirmed hit
-                // closer than nv - 3e-6 makes the ray unlit whatever else lies on it.
-                float tP = __double2float_ru(nv + RT_EPSILON);
-                float tlim = fmaf(tP, RT_2M20, tP + 8e-6f);
-                FastState st;
-                fast_nearest<RT_BLOCK>(S, F, stk, src, dir, tlim, nv - 3e-6, st);
-                lit = !st.stop && (norm3(st.best.p - P) < RT_EPSILON);
-                done = true;
-            }
-            if (!done) {
-                Hit x = nearest_hit_exact(S, src, dir);
-                lit = norm3(x.p - P) < RT_EPSILON;         // Light.py:219-221 (NaN -> unlit)
+            const uint32_t kk = off % s2;
+            const uint32_t a = kk / s, b = kk % s;
+            const SegF hd = bb.seg[seg];
+            if (hd.ncand > RT_CMAX) unsure = true;
+            else {
+                float j1[3] = {0, 0, 0}, j2[3] = {0, 0, 0};
+                if (lp.jitter) {
+                    const uint32_t seg32 = (uint32_t)seg;      // the host enables this kernel only while segments < 2^32
+                    const uint32_t h = seg32 / nsl, ml = seg32 % nsl;
+                    const uint32_t r = hb.list[h];
+                    const uint32_t m = (uint32_t)S.shadow_lights[ml];
+                    const uint32_t pix = q.gpix[r], path = q.path[r];
+                    for (uint32_t stream = 0; stream < 2; ++stream) {
+                        uint32_t x = pix, y = path * 0x9E3779B1u + m, z = lp.seed * 0x85EBCA6Bu + kk * 2u + stream;
+                        pcg3d(x, y, z);
+                        float *j = stream ? j2 : j1;
+                        const float k24 = 1.0f / 16777216.0f;
+                        j[0] = fmaf(2.0f * hd.g, (float)(x >> 8) * k24, -hd.g);
+                        j[1] = fmaf(2.0f * hd.g, (float)(y >> 8) * k24, -hd.g);
+                        j[2] = fmaf(2.0f * hd.g, (float)(z >> 8) * k24, -hd.g);
+                    }
+                }
+                // w = sample - P (Light.py:273-279), float32
+                const float bg = (float)b * hd.g, ag = (float)a * hd.g;
+                float w0 = hd.q0[0] - bg * hd.up[0] + ag * hd.right[0] + (j1[0] * hd.up[0] + j2[0] * hd.right[0]);
+                float w1 = hd.q0[1] - bg * hd.up[1] + ag * hd.right[1] + (j1[1] * hd.up[1] + j2[1] * hd.right[1]);
+                float w2 = hd.q0[2] - bg * hd.up[2] + ag * hd.right[2] + (j1[2] * hd.up[2] + j2[2] * hd.right[2]);
+                const float nv = sqrtf(fmaf(w0, w0, fmaf(w1, w1, w2 * w2)));
+                const float inv_nv = 1.0f / nv;
+                w0 *= inv_nv; w1 *= inv_nv; w2 *= inv_nv;
+                const float i0 = 1.0f / w0, i1 = 1.0f / w1, i2 = 1.0f / w2;
+                int n_atp = 0;
+                bool occl = false;
+                if (!(nv > 1e-4f) || !(nv < 1e7f)) unsure = true;
+                for (int k = 0; k < S.n_planes; ++k) {
+                    int v = sh_plane(S.planes[k], hd.pd[k], w0, w1, w2, nv);
+                    occl = occl || v == SH_OCCLUDE;
+                    unsure = unsure || v == SH_UNSURE;
+                    n_atp += v == SH_ATP;
+                }
+                const CandF *cl = bb.cand + seg * RT_CMAX;
+                for (uint32_t c = 0; c < hd.ncand && !occl; ++c) {
+                    const CandF k = cl[c];
+                    int v = (k.kind & 3u) == 1u ? sh_sphere(k, w0, w1, w2, nv) : sh_box(k, w0, w1, w2, i0, i1, i2, nv);
+                    occl = occl || v == SH_OCCLUDE;
+                    unsure = unsure || v == SH_UNSURE;
+                    n_atp += v == SH_ATP;
+                }
+                if (occl) unsure = false;           // one certain occluder settles the ray
+                else if (!unsure) lit = n_atp > 0;
             }
         }
-        // segmented popcount: consecutive lanes of one (hit, light) pair share a counter
-        unsigned long long litmask = __ballot(lit);
-        uint64_t prev = __shfl_up(seg, 1);
-        bool leader = active && (lane == 0 || prev != seg);
-        unsigned long long leaders = __ballot(leader);
-        if (leader) {
-            unsigned long long above = (lane == 63) ? 0ull : (leaders >> (lane + 1));
-            int next = above ? (lane + 1 + (__ffsll((long long)above) - 1)) : 64;
-            unsigned long long segmask = (next == 64 ? ~0ull : ((1ull << next) - 1ull)) & ~((1ull << lane) - 1ull);
-            uint32_t cnt = (uint32_t)__popcll(litmask & segmask);
-            if (cnt) atomicAdd(&hb.lit[seg], cnt);
+        // undecided rays -> queue (one atomic per wave)
+        unsigned long long um = __ballot(unsure);
+        if (um) {
+            int leader = __ffsll((long long)um) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&bb.queue_n[0], (uint32_t)__popcll(um));
+            base = __shfl(base, leader);
+            if (unsure) {
+                uint32_t at = base + (uint32_t)__popcll(um & ((1ull << lane) - 1ull));
+                if (at < bb.queue_n[1]) bb.queue[at] = g;
+                else ctl->overflow = 1;             // frame is void; the host re-renders with a larger queue
+            }
         }
+        add_lit_counts(hb.lit, active, lit, seg, lane);
+    }
+}
+
+// the rays the filter could not decide, in float64
+__global__ void __launch_bounds__(RT_BLOCK) k_shadow_queue(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb, SegBuf sg,
+                                                           BeamBuf bb, FrameCtl *ctl) {
+    extern __shared__ uint2 lds_stack[];
+    uint2 *stk = lds_stack + threadIdx.x;
+    if (ctl->overflow) return;
+    const uint32_t n = min(bb.queue_n[0], bb.queue_n[1]);
+    const uint32_t s2 = (uint32_t)(lp.sh_rays * lp.sh_rays);
+    ChunkWalk walk(n);
+    uint64_t first;
+    while (walk.next(first)) {
+        uint64_t i = first + threadIdx.x;
+        if (i >= n) continue;
+        const uint64_t g = bb.queue[i];
+        if (shadow_ray_lit<true>(S, F, stk, lp, q, hb, sg, g)) atomicAdd(&hb.lit[g / s2], 1u);
     }
 }
 
@@ -610,6 +758,8 @@ struct rt_ctx {
     FastScene F{};
     size_t lds_bytes = 0;   // per-lane traversal stacks: F.depth * RT_BLOCK * 8
     SegBuf seg{};
+    BeamBuf beam{};
+    uint32_t beam_queue_cap = 0;
     rt_scene_desc host{};   // scalar fields only (camera, settings)
     // frame buffers
     uint64_t cap = 0;       // ray-queue capacity
@@ -826,7 +976,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
             memcpy(&kn[i].a, &cf, 4);
             kn[i].b = ((uint32_t)R << 2) | (uint32_t)axis;
         }
-        if (max_depth > 30) ok = false;   // per-lane stacks must fit the default 64 KB dynamic-LDS limit
+        if (max_depth > 40) ok = false;   // per-lane stacks (12 B per level in the beam kernel) must fit the 160 KB LDS   // per-lane stacks must fit the default 64 KB dynamic-LDS limit
         for (int e = 0; e < s->n_leaf_refs; ++e) {
             const int p = s->leaf_prim[e];
             LeafF &f = lf[e];
@@ -858,6 +1008,15 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
         ctx->F.depth = max_depth;
         ctx->F.ok = ok ? 1 : 0;
         ctx->lds_bytes = ok ? (size_t)max_depth * RT_BLOCK * sizeof(uint2) : 0;
+        if (ok) {
+            // per-lane stacks can exceed the default 64 KB dynamic-LDS limit on deep trees
+            const int big = 160 * 1024;
+            HIP_C(hipFuncSetAttribute((const void *)&k_intersect<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+            HIP_C(hipFuncSetAttribute((const void *)&k_shadow<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+            HIP_C(hipFuncSetAttribute((const void *)&k_shadow_queue, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+            HIP_C(hipFuncSetAttribute((const void *)&k_shadow_setup<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+            HIP_C(hipFuncSetAttribute((const void *)&k_intersect_only<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        }
         if (getenv("RT_AMD_DEBUG")) fprintf(stderr, "[rt_amd] kd view: ok=%d depth=%d lds=%zu B\n", ctx->F.ok, max_depth, ctx->lds_bytes);
     }
 
@@ -970,6 +1129,14 @@ static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
     TRY_A(dalloc(ctx, &sg.ux, nlit)); TRY_A(dalloc(ctx, &sg.uy, nlit)); TRY_A(dalloc(ctx, &sg.uz, nlit));
     TRY_A(dalloc(ctx, &sg.rx, nlit)); TRY_A(dalloc(ctx, &sg.ry, nlit)); TRY_A(dalloc(ctx, &sg.rz, nlit));
     TRY_A(dalloc(ctx, &sg.cx, nlit)); TRY_A(dalloc(ctx, &sg.cy, nlit)); TRY_A(dalloc(ctx, &sg.cz, nlit));
+    BeamBuf &bb = ctx->beam;
+    ctx->beam_queue_cap = (uint32_t)(cap < 0x7fffffffull ? cap : 0x7fffffffull);
+    TRY_A(dalloc(ctx, &bb.seg, nlit)); TRY_A(dalloc(ctx, &bb.cand, nlit * RT_CMAX));
+    TRY_A(dalloc(ctx, &bb.queue, (uint64_t)ctx->beam_queue_cap)); TRY_A(dalloc(ctx, &bb.queue_n, 2));
+    {
+        uint32_t init[2] = {0u, ctx->beam_queue_cap};
+        HIP_TRY(ctx, hipMemcpy(bb.queue_n, init, sizeof(init), hipMemcpyHostToDevice));
+    }
     TRY_A(dalloc(ctx, &ctx->fb, slots * 3));
 #undef TRY_A
     ctx->cap = cap;
@@ -1056,6 +1223,8 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
     dim3 grid(ctx->grid), block(RT_BLOCK);
     const bool prof = (p->flags & RT_FLAG_PROFILE) != 0;
     const bool fast = ctx->F.ok && !(p->flags & RT_FLAG_EXACT_TRAVERSAL);
+    const bool beam = fast && ctx->S.n_planes <= RT_PMAX && !(p->flags & RT_FLAG_NO_BEAM) &&
+                      ctx->cap * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1) < 0xFFFFFFFFull;
     for (int level = 0; level <= rec; ++level) {
         lp.level = level;
         lp.last_level = (level == rec) ? 1 : 0;
@@ -1067,9 +1236,16 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         PROF_MARK(e + 1);
         PROF_MARK(e + 2);
         if (ctx->S.n_shadow_lights > 0) {
-            hipLaunchKernelGGL(k_shadow_setup, grid, block, 0, st, ctx->S, lp, ctx->hb, ctx->seg, ctx->ctl);
-            if (fast) hipLaunchKernelGGL(k_shadow<true>, grid, block, ctx->lds_bytes, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->seg, ctx->ctl);
-            else hipLaunchKernelGGL(k_shadow<false>, grid, block, 0, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->seg, ctx->ctl);
+            if (beam) {
+                HIP_TRY(ctx, hipMemsetAsync(ctx->beam.queue_n, 0, sizeof(uint32_t), st));
+                hipLaunchKernelGGL(k_shadow_setup<true>, grid, block, ctx->lds_bytes * 3 / 2, st, ctx->S, ctx->F, lp, ctx->hb, ctx->seg, ctx->beam, ctx->ctl);
+                hipLaunchKernelGGL(k_shadow_beam, grid, block, 0, st, ctx->S, lp, qc, ctx->hb, ctx->beam, ctx->ctl);
+                hipLaunchKernelGGL(k_shadow_queue, grid, block, ctx->lds_bytes, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->seg, ctx->beam, ctx->ctl);
+            } else {
+                hipLaunchKernelGGL(k_shadow_setup<false>, grid, block, 0, st, ctx->S, ctx->F, lp, ctx->hb, ctx->seg, ctx->beam, ctx->ctl);
+                if (fast) hipLaunchKernelGGL(k_shadow<true>, grid, block, ctx->lds_bytes, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->seg, ctx->ctl);
+                else hipLaunchKernelGGL(k_shadow<false>, grid, block, 0, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->seg, ctx->ctl);
+            }
         }
         PROF_MARK(e + 3);
         PROF_MARK(e + 4);

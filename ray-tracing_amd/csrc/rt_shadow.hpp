@@ -1,0 +1,230 @@
+// rt_shadow.hpp - soft shadows as filtered predicates (Light.compute_shadows, Light.py:178-227).
+//
+// The reference decides a shadow ray by  lit <=> |X - P| < 1e-6  where X is the nearest hit of the
+// ray from the light sample to the shaded point P.  Seen from P (tau = distance from P toward the
+// sample), every primitive the line meets has a point tau_out where the light ray ENTERS it; X is
+// the entry with the largest tau_out below the sample, so
+//
+//     some primitive has  tau_out >  1e-6                      -> unlit   ("OCCLUDE")
+//     all primitives have tau_out < -1e-6 or miss the line,
+//       and one has |tau_out| < 1e-6                           -> lit     ("AT_P": P's own surface)
+//
+// All s*s rays of one (hit, light) pair end in the same P and start inside one small box around the
+// light, so (1) ONE conservative beam traversal per pair (k_shadow_setup) collects the few
+// primitives any of its rays can touch, with their coordinates taken RELATIVE TO P in float64 and
+// only then rounded to float32 - the own surface sits at ~1e-16, not at an ulp of a world
+// coordinate; (2) each ray classifies those candidates in float32 with explicit error margins
+// (k_shadow_beam).  A verdict is only taken when every margin is cleared; anything else (grazing
+// silhouettes, |w.n| ~ 0, sample inside a primitive, candidate-list overflow) is appended to a
+// queue and decided by the float64 path of rt_fast.hpp (k_shadow_queue).  So the outcome is that
+// of the float64 reference-order evaluation, at float32 VALU cost for ~99.9 % of the rays.
+#pragma once
+#include "rt_fast.hpp"
+
+#define RT_CMAX 8            // candidate primitives kept per (hit, light) pair
+#define RT_PMAX 4            // planes handled by the filtered path
+
+struct CandF {               // 32 B, coordinates relative to P
+    float a[3];              // sphere: centre - P                      box: lo - P rounded down
+    float c;                 // sphere: |centre - P|^2 - r^2 (from float64)
+    float b[3];              // box: hi - P rounded up
+    uint32_t kind;           // 1 sphere, 2 box
+};
+struct SegF {                // 64 B header per (hit, light) pair
+    float q0[3];             // p00 - P  (Light.py:260), from float64
+    float g;                 // radius / s
+    float up[3];
+    uint32_t ncand;          // RT_CMAX + 1 = overflow: every ray of the pair goes to the queue
+    float right[3];
+    float pad;
+    float pd[RT_PMAX];       // plane k: n_k . P + d_k (from float64; ~1e-16 on P's own plane)
+};
+struct BeamBuf {
+    SegF *seg;
+    CandF *cand;             // [segment][RT_CMAX]
+    unsigned long long *queue;   // shadow-ray numbers g the filter could not decide
+    uint32_t *queue_n;       // [0] = entries appended, [1] = capacity
+};
+
+#define RT_T1 1e-6f          // the reference's EPSILON (Light.py:221)
+#define RT_RHO 1.9073486e-06f   // 2^-19: relative margin on every tau (direction error 2^-20 + arithmetic)
+
+enum { SH_MISS = 0, SH_ATP = 1, SH_OCCLUDE = 2, SH_UNSURE = 3 };
+
+// verdict for one primitive from conservative bounds [lo, hi] of tau_out; nv = |sample - P|
+__device__ __forceinline__ int sh_classify(float lo, float hi, float nv) {
+    if (!(lo <= hi)) return SH_UNSURE;                             // NaN somewhere
+    if (hi < -1.1f * RT_T1) return SH_MISS;                         // entirely behind P
+    if (lo > 1.1f * RT_T1) return (hi < nv - fmaf(nv, 4.0f * RT_RHO, 1e-5f)) ? SH_OCCLUDE : SH_UNSURE;
+    if (lo > -0.9f * RT_T1 && hi < 0.9f * RT_T1) return SH_ATP;
+    return SH_UNSURE;
+}
+
+__device__ __forceinline__ int sh_sphere(const CandF &k, float w0, float w1, float w2, float nv) {
+    const float b = fmaf(w0, k.a[0], fmaf(w1, k.a[1], w2 * k.a[2]));
+    const float eb = 1.5f * RT_RHO * (fabsf(w0 * k.a[0]) + fabsf(w1 * k.a[1]) + fabsf(w2 * k.a[2])) +
+                     RT_RHO * 0.5f * (fabsf(k.a[0]) + fabsf(k.a[1]) + fabsf(k.a[2]));
+    const float disc = fmaf(b, b, -k.c);
+    const float ed = fmaf(2.0f * fabsf(b), eb, eb * eb) + 4.8e-7f * (b * b + fabsf(k.c));
+    if (disc < -ed) return SH_MISS;                                 // the line misses the sphere
+    if (!(disc > ed)) return SH_UNSURE;                             // grazing
+    const float sl = sqrtf(disc - ed) * (1.0f - 4.8e-7f), sh = sqrtf(disc + ed) * (1.0f + 4.8e-7f);
+    float lo, hi;
+    if (b >= eb) {                    // centre on the light side: tau_out = b + sqrt(disc)
+        lo = (b - eb) + sl;
+        hi = (b + eb) + sh;
+    } else if (b <= -eb) {            // centre away from the light: tau_out = c / (b - sqrt(disc)), stable form
+        const float qlo = (b - eb) - sh, qhi = (b + eb) - sl;      // both negative
+        const float clo = k.c - fabsf(k.c) * 4.8e-7f, chi = k.c + fabsf(k.c) * 4.8e-7f;
+        if (!(qhi < 0.0f)) return SH_UNSURE;
+        if (clo >= 0.0f) { lo = chi / qhi; hi = clo / qlo; }       // c >= 0: tau_out <= 0
+        else if (chi <= 0.0f) { lo = chi / qlo; hi = clo / qhi; }  // c <= 0: tau_out >= 0
+        else { lo = chi / qhi; hi = clo / qhi; }
+        lo -= fabsf(lo) * 4.8e-7f;
+        hi += fabsf(hi) * 4.8e-7f;
+    } else return SH_UNSURE;
+    return sh_classify(lo, hi, nv);
+}
+
+__device__ __forceinline__ int sh_box(const CandF &k, float w0, float w1, float w2, float i0, float i1, float i2, float nv) {
+    if (fabsf(w0) < 4e-6f || fabsf(w1) < 4e-6f || fabsf(w2) < 4e-6f) return SH_UNSURE;   // nearly axis parallel
+    float a0 = k.a[0] * i0, b0 = k.b[0] * i0, a1 = k.a[1] * i1, b1 = k.b[1] * i1, a2 = k.a[2] * i2, b2 = k.b[2] * i2;
+    float n0 = fminf(a0, b0), x0 = fmaxf(a0, b0), n1 = fminf(a1, b1), x1 = fmaxf(a1, b1), n2 = fminf(a2, b2), x2 = fmaxf(a2, b2);
+    // the direction error is ABSOLUTE (<= 2^-20 per component), so the relative error of a slab distance
+    // along axis k is 2^-20 / |w_k| (+ arithmetic)
+    const float r0 = fmaf(RT_2M20, fabsf(i0), RT_2M20), r1 = fmaf(RT_2M20, fabsf(i1), RT_2M20), r2 = fmaf(RT_2M20, fabsf(i2), RT_2M20);
+    float en_lo = fmaxf(fmaxf(n0 - fabsf(n0) * r0, n1 - fabsf(n1) * r1), n2 - fabsf(n2) * r2);
+    float en_hi = fmaxf(fmaxf(n0 + fabsf(n0) * r0, n1 + fabsf(n1) * r1), n2 + fabsf(n2) * r2);
+    float ex_lo = fminf(fminf(x0 - fabsf(x0) * r0, x1 - fabsf(x1) * r1), x2 - fabsf(x2) * r2);
+    float ex_hi = fminf(fminf(x0 + fabsf(x0) * r0, x1 + fabsf(x1) * r1), x2 + fabsf(x2) * r2);
+    if (en_lo > ex_hi) return SH_MISS;                              // the line misses the box
+    if (!(en_hi < ex_lo)) return SH_UNSURE;                         // touching an edge / corner
+    return sh_classify(ex_lo, ex_hi, nv);                           // the light ray enters at tau = exit
+}
+
+__device__ __forceinline__ int sh_plane(const DPlane &pl, float pd, float w0, float w1, float w2, float nv) {
+    const float n0 = (float)pl.n[0], n1 = (float)pl.n[1], n2 = (float)pl.n[2];
+    const float vn = fmaf(w0, n0, fmaf(w1, n1, w2 * n2));
+    const float ev = 2.0f * RT_RHO;
+    if (vn < -ev) return SH_MISS;                                   // the light ray sees the back: one-sided (InfinitePlane.py:83)
+    if (!(vn > ev)) return SH_UNSURE;
+    // tau = -pd / vn
+    const float num = -pd;
+    float lo, hi;
+    if (num >= 0.0f) { lo = num * (1.0f - 4.8e-7f) / (vn + ev); hi = num * (1.0f + 4.8e-7f) / (vn - ev); }
+    else { lo = num * (1.0f + 4.8e-7f) / (vn - ev); hi = num * (1.0f - 4.8e-7f) / (vn + ev); }
+    lo -= fabsf(lo) * 4.8e-7f;
+    hi += fabsf(hi) * 4.8e-7f;
+    if (lo > nv + fmaf(nv, 4.0f * RT_RHO, 1e-5f)) return SH_MISS;   // plane beyond the sample (t < 0 from the light)
+    return sh_classify(lo, hi, nv);
+}
+
+// ---------------------------------------------------------------------------------------------
+// beam traversal: all points  lambda * s,  s in [cB - h, cB + h], lambda in [0, 1]  (P at the origin)
+// ---------------------------------------------------------------------------------------------
+// keep the part of [l0, l1] where  lambda * coef <= rhs
+__device__ __forceinline__ void clip_le(float &l0, float &l1, float coef, float rhs) {
+    if (coef > 0.0f) l1 = fminf(l1, rhs / coef);
+    else if (coef < 0.0f) l0 = fmaxf(l0, rhs / coef);
+    else if (rhs < 0.0f) l1 = -1.0f;                 // 0 <= rhs fails: empty
+}
+__device__ __forceinline__ void clip_ge(float &l0, float &l1, float coef, float rhs) { clip_le(l0, l1, -coef, -rhs); }
+
+struct BeamStack {           // LDS columns, one entry per tree level
+    uint2 *a;                // (node, lambda0 bits)
+    float *b;                // lambda1
+};
+
+// returns the number of candidates written (RT_CMAX + 1 on overflow)
+template <int STRIDE>
+__device__ __forceinline__ uint32_t beam_collect(const DScene &S, const FastScene &F, BeamStack stk, d3 P, const float cB[3],
+                                                 const float h[3], CandF *out) {
+    const float Pf[3] = {(float)P.x, (float)P.y, (float)P.z};
+    const float Pl[3] = {(float)(P.x - (double)Pf[0]), (float)(P.y - (double)Pf[1]), (float)(P.z - (double)Pf[2])};
+    const float Kp = fmaxf(fmaxf(fabsf(Pf[0]), fabsf(Pf[1])), fmaxf(fabsf(Pf[2]), F.extent));
+    const float E = Kp * RT_2M19 + 2e-6f;            // absolute slack on every plane position (rounding of cut, P, and 1e-6 offsets)
+    float L[3], U[3];
+    for (int k = 0; k < 3; ++k) { L[k] = cB[k] - h[k]; U[k] = cB[k] + h[k]; }
+    float l0 = 0.0f, l1 = 1.0f;
+    for (int k = 0; k < 3; ++k) {                    // root box relative to P
+        const float rlo = (F.root_lo[k] - Pf[k]) - Pl[k] - E, rhi = (F.root_hi[k] - Pf[k]) - Pl[k] + E;
+        clip_ge(l0, l1, U[k], rlo);
+        clip_le(l0, l1, L[k], rhi);
+    }
+    uint32_t n = 0;
+    if (!(l0 <= l1)) return 0;
+    uint32_t node = 0;
+    int sp = 0;
+    for (;;) {
+        KNode nd = F.knodes[node];
+        bool dead = false;
+        while ((nd.b & 3u) != 3u) {
+            const uint32_t ax = nd.b & 3u;
+            const float cut = (__uint_as_float(nd.a) - Pf[ax]) - Pl[ax];
+            float a0 = l0, a1 = l1, b0 = l0, b1 = l1;
+            clip_le(a0, a1, L[ax], cut + E);         // left child: some beam point with x <= cut
+            clip_ge(b0, b1, U[ax], cut - E);         // right child
+            const bool goL = a0 <= a1, goR = b0 <= b1;
+            if (goL && goR) {
+                stk.a[sp * STRIDE] = make_uint2(nd.b >> 2, __float_as_uint(b0));
+                stk.b[sp * STRIDE] = b1;
+                ++sp;
+            }
+            if (goL) { node = node + 1; l0 = a0; l1 = a1; }
+            else if (goR) { node = nd.b >> 2; l0 = b0; l1 = b1; }
+            else { dead = true; break; }
+            nd = F.knodes[node];
+        }
+        if (!dead) {
+            // beam bounding box over this leaf's lambda range (slightly widened)
+            const float m0 = fmaxf(l0 - 1e-6f, 0.0f), m1 = fminf(l1 + 1e-6f, 1.0f);
+            float blo[3], bhi[3];
+            for (int k = 0; k < 3; ++k) {
+                blo[k] = fminf(m0 * L[k], m1 * L[k]) - E;
+                bhi[k] = fmaxf(m0 * U[k], m1 * U[k]) + E;
+            }
+            const uint32_t first = nd.a, cnt = nd.b >> 2;
+            for (uint32_t e = first; e < first + cnt; ++e) {
+                const LeafF lf = F.leaves[e];
+                const uint32_t kind = lf.pk & 3u, prim = lf.pk >> 2;
+                float plo[3], phi[3];
+                if (kind == 1u) {
+                    const float c0 = (lf.x - Pf[0]) + (lf.lx - Pl[0]), c1 = (lf.y - Pf[1]) + (lf.ly - Pl[1]), c2 = (lf.z - Pf[2]) + (lf.lz - Pl[2]);
+                    plo[0] = c0 - lf.r; plo[1] = c1 - lf.r; plo[2] = c2 - lf.r;
+                    phi[0] = c0 + lf.r; phi[1] = c1 + lf.r; phi[2] = c2 + lf.r;
+                } else {
+                    plo[0] = (lf.x - Pf[0]) - Pl[0]; plo[1] = (lf.y - Pf[1]) - Pl[1]; plo[2] = (lf.z - Pf[2]) - Pl[2];
+                    phi[0] = (lf.lx - Pf[0]) - Pl[0]; phi[1] = (lf.ly - Pf[1]) - Pl[1]; phi[2] = (lf.lz - Pf[2]) - Pl[2];
+                }
+                bool touch = true;
+                for (int k = 0; k < 3; ++k) touch = touch && !(plo[k] > bhi[k]) && !(phi[k] < blo[k]);
+                if (!touch) continue;
+                bool seen = false;                   // the same primitive is listed in several leaves
+                for (uint32_t j = 0; j < n; ++j) seen = seen || (out[j].kind >> 2) == prim;
+                if (seen) continue;
+                if (n == RT_CMAX) return RT_CMAX + 1;
+                const DPrim *pr = S.prims + prim;
+                CandF c;
+                if (kind == 1u) {
+                    const double dx = pr->a[0] - P.x, dy = pr->a[1] - P.y, dz = pr->a[2] - P.z;
+                    c.a[0] = (float)dx; c.a[1] = (float)dy; c.a[2] = (float)dz;
+                    c.c = (float)(((dx * dx + dy * dy) + dz * dz) - pr->b[0]);
+                    c.b[0] = c.b[1] = c.b[2] = 0.0f;
+                } else {
+                    c.a[0] = __double2float_rd(pr->a[0] - P.x); c.a[1] = __double2float_rd(pr->a[1] - P.y); c.a[2] = __double2float_rd(pr->a[2] - P.z);
+                    c.b[0] = __double2float_ru(pr->b[0] - P.x); c.b[1] = __double2float_ru(pr->b[1] - P.y); c.b[2] = __double2float_ru(pr->b[2] - P.z);
+                    c.c = 0.0f;
+                }
+                c.kind = (prim << 2) | kind;
+                out[n] = c;
+                ++n;
+            }
+        }
+        if (sp == 0) return n;
+        --sp;
+        const uint2 t = stk.a[sp * STRIDE];
+        node = t.x;
+        l0 = __uint_as_float(t.y);
+        l1 = stk.b[sp * STRIDE];
+    }
+}

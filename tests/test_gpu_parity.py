@@ -185,18 +185,21 @@ def test_bad_arguments_are_reported(gpu_ctx):
 
 # ------------------------------------------------------------------ fast path == exact walk
 @pytest.mark.parametrize("tag,w,h,sh,rec", [("small", 160, 100, 3, 5), ("original", 200, 200, 2, 10),
-                                            ("pool", 320, 180, 5, 10), ("synth400", 320, 180, 5, 5)])
+                                            ("pool", 320, 180, 5, 10), ("synth400", 320, 180, 5, 5),
+                                            ("pool", 640, 360, 1, 10), ("small", 320, 200, 1, 2)])
 def test_fast_traversal_equals_reference_order_walk(gpu_ctx, tag, w, h, sh, rec):
     """float32-culled kd traversal (default) against the float64 reference-order walk
     (RT_FLAG_EXACT_TRAVERSAL): ids, ray counts and the float32 image must be identical."""
     ctx = gpu_ctx(tag)
-    fast = ctx.render(abi.render_params(w, h, sh_rays=sh, rec_max=rec, jitter=True, seed=42))
     exact = ctx.render(abi.render_params(w, h, sh_rays=sh, rec_max=rec, jitter=True, seed=42,
                                          flags=abi.RT_FLAG_EXACT_TRAVERSAL))
-    assert np.array_equal(fast["ids"], exact["ids"])
-    assert fast["stats"]["rays"] == exact["stats"]["rays"]
-    assert np.array_equal(fast["rgb8"], exact["rgb8"])
-    assert np.abs(fast["rgb"] - exact["rgb"]).max() < 1e-6
+    # default = beam + float32 filtered shadow predicates; NO_BEAM = one float64-confirmed traversal per shadow ray
+    for flags in (0, abi.RT_FLAG_NO_BEAM):
+        fast = ctx.render(abi.render_params(w, h, sh_rays=sh, rec_max=rec, jitter=True, seed=42, flags=flags))
+        assert np.array_equal(fast["ids"], exact["ids"])
+        assert fast["stats"]["rays"] == exact["stats"]["rays"]
+        assert np.array_equal(fast["rgb8"], exact["rgb8"])
+        assert np.array_equal(fast["rgb"], exact["rgb"])      # same lit counts -> same float64 sums
 
 
 def test_fast_intersect_axis_parallel_and_degenerate_rays(gpu_ctx, oracle):
