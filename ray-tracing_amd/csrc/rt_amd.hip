@@ -76,6 +76,8 @@ struct LevelParams {
     int32_t sh_rays, jitter;
     uint32_t seed, cap;
     int32_t flags;
+    // beam path: a chunk of RT_BLOCK lanes holds spb whole (hit, light) pairs of s2 rays each
+    uint32_t spb, magic_s2, magic_s;     // magic_x = ceil(2^32 / x): n / x == __umulhi(n, magic_x) for n < 2^16
 };
 
 // XCD-aware chunk walk: workgroups b and b+8 share an XCD (and its L2), so XCD x = b % 8 walks one
@@ -283,12 +285,20 @@ __global__ void __launch_bounds__(RT_BLOCK) k_intersect(DScene S, FastScene F, L
     }
 }
 
-// light-plane basis once per (hit, shadow light) (Light.py:252-260); the s*s lanes of a segment reuse it.
-// BEAM: additionally the float32 header and the candidate list of the filtered path (rt_shadow.hpp).
-template <bool BEAM>
-__global__ void __launch_bounds__(RT_BLOCK) k_shadow_setup(DScene S, FastScene F, LevelParams lp, HitBuf hb, SegBuf sg,
-                                                           BeamBuf bb, FrameCtl *ctl) {
-    extern __shared__ uint2 lds_stack[];
+// exact light-plane basis of one (hit, light) pair (Light.py:48-50,252-260)
+__device__ __forceinline__ void exact_basis(const DLight &Lt, int sh_rays, d3 P, d3 &up, d3 &right, d3 &p00) {
+    d3 lpos = ld3(Lt.pos);
+    d3 dl = lpos - P;                              // Light.py:48-50
+    d3 L = dl / norm3(dl);
+    light_basis(neg3(L), up, right);               // Light.py:257
+    double radius = Lt.radius;
+    double gsz = radius / (double)sh_rays;         // Light.py:254
+    double c0 = (radius - gsz) / 2;
+    p00 = (lpos + c0 * up) - c0 * right;           // Light.py:260
+}
+
+// NO_BEAM / exact modes: the float64 basis once per (hit, shadow light); k_shadow's s*s lanes of a pair reuse it
+__global__ void __launch_bounds__(RT_BLOCK) k_shadow_setup(DScene S, LevelParams lp, HitBuf hb, SegBuf sg, FrameCtl *ctl) {
     if (ctl->overflow) return;
     const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
     const uint32_t nsl = (uint32_t)S.n_shadow_lights;
@@ -300,55 +310,91 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_setup(DScene S, FastScene F
         if (seg >= total) continue;
         uint32_t h = (uint32_t)(seg / nsl), ml = (uint32_t)(seg % nsl);
         uint32_t r = hb.list[h];
-        int m = S.shadow_lights[ml];
         d3 P = mk3(hb.px[r], hb.py[r], hb.pz[r]);
-        const DLight &Lt = S.lights[m];
-        d3 lpos = ld3(Lt.pos);
-        d3 dl = lpos - P;                              // Light.py:48-50
-        d3 L = dl / norm3(dl);
-        d3 up, right;
-        light_basis(neg3(L), up, right);               // Light.py:257
-        double radius = Lt.radius;
-        double gsz = radius / (double)lp.sh_rays;      // Light.py:254
-        double c0 = (radius - gsz) / 2;
-        d3 p00 = (lpos + c0 * up) - c0 * right;        // Light.py:260
+        d3 up, right, p00;
+        exact_basis(S.lights[S.shadow_lights[ml]], lp.sh_rays, P, up, right, p00);
         sg.ux[seg] = up.x; sg.uy[seg] = up.y; sg.uz[seg] = up.z;
         sg.rx[seg] = right.x; sg.ry[seg] = right.y; sg.rz[seg] = right.z;
         sg.cx[seg] = p00.x; sg.cy[seg] = p00.y; sg.cz[seg] = p00.z;
-        if (BEAM) {
-            SegF hd;
-            d3 q0 = p00 - P;
-            hd.q0[0] = (float)q0.x; hd.q0[1] = (float)q0.y; hd.q0[2] = (float)q0.z;
-            hd.g = (float)gsz;
-            hd.up[0] = (float)up.x; hd.up[1] = (float)up.y; hd.up[2] = (float)up.z;
-            hd.right[0] = (float)right.x; hd.right[1] = (float)right.y; hd.right[2] = (float)right.z;
-            hd.pad = 0.0f;
-            for (int k = 0; k < RT_PMAX; ++k) hd.pd[k] = 0.0f;
-            for (int k = 0; k < S.n_planes && k < RT_PMAX; ++k) {
-                const DPlane &pl = S.planes[k];
-                hd.pd[k] = (float)(dot3(ld3(pl.n), P) + pl.d);
-            }
-            // box of every sample origin of the pair, relative to P: grid points a,b in [0,s-1] and the
-            // component-wise deviations of Light.py:277-279 (|u| <= g on each of up and right)
-            const float sm1 = (float)(lp.sh_rays - 1);
-            float cB[3], hh[3];
-            for (int k = 0; k < 3; ++k) {
-                cB[k] = hd.q0[k] + 0.5f * sm1 * hd.g * (hd.right[k] - hd.up[k]);
-                hh[k] = (0.5f * sm1 + 1.0f) * hd.g * (fabsf(hd.up[k]) + fabsf(hd.right[k]));
-                hh[k] = fmaf(RT_2M19, fabsf(cB[k]) + hh[k], hh[k]) + 1e-6f;
-            }
-            bool tame = ray_is_tame(P, L) && fabs(q0.x) < 1e7 && fabs(q0.y) < 1e7 && fabs(q0.z) < 1e7;
-            BeamStack bs;
-            bs.a = lds_stack + threadIdx.x;
-            bs.b = (float *)(lds_stack + (size_t)F.depth * RT_BLOCK) + threadIdx.x;
-            hd.ncand = tame ? beam_collect<RT_BLOCK>(S, F, bs, P, cB, hh, bb.cand + seg * RT_CMAX) : RT_CMAX + 1;
-            bb.seg[seg] = hd;
+    }
+}
+
+// beam path: float32 header + candidate list of every (hit, shadow light) pair (rt_shadow.hpp).  The basis is
+// computed in float32 from the float64 difference light - P; its error is part of the direction-error budget
+// RT_RHO of the per-ray predicates.  Pairs whose basis is numerically delicate are marked "overflow": all their
+// rays are then decided by the float64 path.
+__global__ void __launch_bounds__(RT_BLOCK) k_beam_setup(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb, BeamBuf bb,
+                                                         FrameCtl *ctl) {
+    extern __shared__ uint2 lds_stack[];
+    if (ctl->overflow) return;
+    const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
+    const uint32_t nsl = (uint32_t)S.n_shadow_lights;
+    const uint32_t total = n_hits * nsl;           // < 2^32: checked on the host
+    ChunkWalk walk(total);
+    uint64_t first;
+    while (walk.next(first)) {
+        const uint32_t seg = (uint32_t)first + threadIdx.x;
+        if (seg >= total) continue;
+        const uint32_t h = seg / nsl, ml = seg - h * nsl;
+        const uint32_t r = hb.list[h];
+        const int m = S.shadow_lights[ml];
+        const d3 P = mk3(hb.px[r], hb.py[r], hb.pz[r]);
+        const DLight &Lt = S.lights[m];
+        const d3 dl = ld3(Lt.pos) - P;
+        SegF hd;
+        hd.pix = q.gpix[r];
+        hd.path = q.path[r];
+        // D = -(light - P)/|light - P|  (Light.py:81: light_direction = -L)
+        const float e0 = (float)dl.x, e1 = (float)dl.y, e2 = (float)dl.z;
+        const float il = 1.0f / sqrtf(fmaf(e0, e0, fmaf(e1, e1, e2 * e2)));
+        const float D0 = -e0 * il, D1 = -e1 * il, D2 = -e2 * il;
+        // util.get_orthonormal_vector: the branch is taken on the float64 value of D.z (Q7)
+        const double az = fabs(dl.z), an = fabs(dl.x) + fabs(dl.y) + az;
+        bool delicate = !(an > 0.0) || !(an < 1e7) || !ray_is_tame(P, dl);
+        float u0 = 1.0f, u1 = 1.0f, u2 = 0.0f;
+        if (dl.z != 0.0) {
+            if (az < 1e-280 * an || fabsf(D2) < 1e-12f) delicate = true;   // D.z would underflow, or (1,1,u3) overflows float32
+            u2 = -(D0 + D1) / D2;
         }
+        const float iu = 1.0f / sqrtf(2.0f + u2 * u2);
+        u0 *= iu; u1 *= iu; u2 *= iu;
+        float r0 = u1 * D2 - u2 * D1, r1 = u2 * D0 - u0 * D2, r2 = u0 * D1 - u1 * D0;     // np.cross(up, D)
+        const float ir = 1.0f / (sqrtf(fmaf(r0, r0, fmaf(r1, r1, r2 * r2))) + 1e-6f);
+        r0 *= ir; r1 *= ir; r2 *= ir;
+        const float radius = (float)Lt.radius;
+        hd.g = radius / (float)lp.sh_rays;
+        const float c0 = (radius - hd.g) * 0.5f;
+        hd.q0[0] = e0 + c0 * (u0 - r0); hd.q0[1] = e1 + c0 * (u1 - r1); hd.q0[2] = e2 + c0 * (u2 - r2);
+        hd.up[0] = u0; hd.up[1] = u1; hd.up[2] = u2;
+        hd.right[0] = r0; hd.right[1] = r1; hd.right[2] = r2;
+#pragma unroll
+        for (int k = 0; k < RT_PMAX; ++k) {
+            float v = 0.0f;
+            if (k < S.n_planes) v = (float)(dot3(ld3(S.planes[k].n), P) + S.planes[k].d);
+            hd.pd[k] = v;
+        }
+        // box of every sample origin of the pair, relative to P: grid points a,b in [0,s-1] and the
+        // component-wise deviations of Light.py:277-279 (|u| <= g on each of up and right)
+        const float sm1 = (float)(lp.sh_rays - 1);
+        const float cB0 = hd.q0[0] + 0.5f * sm1 * hd.g * (r0 - u0), cB1 = hd.q0[1] + 0.5f * sm1 * hd.g * (r1 - u1),
+                    cB2 = hd.q0[2] + 0.5f * sm1 * hd.g * (r2 - u2);
+        float h0 = (0.5f * sm1 + 1.0f) * hd.g * (fabsf(u0) + fabsf(r0)), h1 = (0.5f * sm1 + 1.0f) * hd.g * (fabsf(u1) + fabsf(r1)),
+              h2 = (0.5f * sm1 + 1.0f) * hd.g * (fabsf(u2) + fabsf(r2));
+        h0 = fmaf(RT_2M18, fabsf(cB0) + h0, h0) + 1e-5f;
+        h1 = fmaf(RT_2M18, fabsf(cB1) + h1, h1) + 1e-5f;
+        h2 = fmaf(RT_2M18, fabsf(cB2) + h2, h2) + 1e-5f;
+        BeamStack bs;
+        bs.a = lds_stack + threadIdx.x;
+        bs.b = (float *)(lds_stack + (size_t)F.depth * RT_BLOCK) + threadIdx.x;
+        uint32_t nc = RT_CMAX + 1;
+        if (!delicate) nc = beam_collect<RT_BLOCK>(S, F, bs, P, cB0, cB1, cB2, h0, h1, h2, bb.cand + (uint64_t)seg * RT_CMAX);
+        hd.meta = nc | ((uint32_t)m << 8);
+        bb.seg[seg] = hd;
     }
 }
 
 // float64-confirmed verdict for shadow ray g (rt_fast.hpp), or the reference-order walk when !FAST
-template <bool FAST>
+template <bool FAST, bool STORED>
 __device__ __forceinline__ bool shadow_ray_lit(const DScene &S, const FastScene &F, uint2 *stk, const LevelParams &lp,
                                                const RayQ &q, const HitBuf &hb, const SegBuf &sg, uint64_t g) {
     const uint32_t s = (uint32_t)lp.sh_rays, s2 = s * s;
@@ -359,9 +405,12 @@ __device__ __forceinline__ bool shadow_ray_lit(const DScene &S, const FastScene 
     uint32_t r = hb.list[h];
     int m = S.shadow_lights[ml];
     d3 P = mk3(hb.px[r], hb.py[r], hb.pz[r]);
-    d3 up = mk3(sg.ux[seg], sg.uy[seg], sg.uz[seg]);
-    d3 right = mk3(sg.rx[seg], sg.ry[seg], sg.rz[seg]);
-    d3 p00 = mk3(sg.cx[seg], sg.cy[seg], sg.cz[seg]);
+    d3 up, right, p00;
+    if (STORED) {
+        up = mk3(sg.ux[seg], sg.uy[seg], sg.uz[seg]);
+        right = mk3(sg.rx[seg], sg.ry[seg], sg.rz[seg]);
+        p00 = mk3(sg.cx[seg], sg.cy[seg], sg.cz[seg]);
+    } else exact_basis(S.lights[m], lp.sh_rays, P, up, right, p00);
     double gsz = S.lights[m].radius / (double)(int)s;          // Light.py:254
     d3 src = (p00 - ((double)b * gsz) * up) + ((double)a * gsz) * right;   // Light.py:273-274
     d3 u1 = mk3(0, 0, 0), u2 = mk3(0, 0, 0);
@@ -419,59 +468,58 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene S, FastScene F, Leve
         uint64_t g = first + threadIdx.x;
         bool active = g < total;
         uint64_t seg = active ? g / s2 : ~0ull;       // (hit, light) pair: h * nsl + ml
-        bool lit = active && shadow_ray_lit<FAST>(S, F, stk, lp, q, hb, sg, g);
+        bool lit = active && shadow_ray_lit<FAST, true>(S, F, stk, lp, q, hb, sg, g);
         add_lit_counts(hb.lit, active, lit, seg, lane);
     }
 }
 
 // one lane per soft-shadow ray, float32 filtered predicates on the pair's candidate list (rt_shadow.hpp);
-// undecided rays go to the queue
-__global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams lp, RayQ q, HitBuf hb, BeamBuf bb, FrameCtl *ctl) {
+// undecided rays go to the queue.  A chunk of RT_BLOCK lanes holds lp.spb whole pairs.
+__global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams lp, HitBuf hb, BeamBuf bb, FrameCtl *ctl) {
     if (ctl->overflow) return;
     const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
     const uint32_t s = (uint32_t)lp.sh_rays, s2 = s * s;
-    const uint32_t nsl = (uint32_t)S.n_shadow_lights;
-    const uint64_t total = (uint64_t)n_hits * nsl * s2;
-    ChunkWalk walk(total);
+    const uint32_t nseg = n_hits * (uint32_t)S.n_shadow_lights;
+    const uint32_t nchunks = (nseg + lp.spb - 1) / lp.spb;
+    ChunkWalk walk((uint64_t)nchunks * RT_BLOCK);
     uint64_t first;
     const int lane = threadIdx.x & 63;
+    const uint32_t sib = s2 == 1 ? threadIdx.x : __umulhi(threadIdx.x, lp.magic_s2);   // pair within the chunk
+    const uint32_t kk = threadIdx.x - sib * s2;                        // sample within the pair
+    const uint32_t a = s == 1 ? kk : __umulhi(kk, lp.magic_s), b = kk - a * s;   // Light.py:265: jj = a, ii = b
+    float pn[RT_PMAX][3];
+    for (int k = 0; k < RT_PMAX; ++k)
+        for (int c = 0; c < 3; ++c) pn[k][c] = k < S.n_planes ? (float)S.planes[k].n[c] : 0.0f;
     while (walk.next(first)) {
-        // first is a multiple of RT_BLOCK: split it once per chunk (uniform), then 32-bit arithmetic per lane
-        const uint64_t seg0 = first / s2;
-        const uint32_t rem0 = (uint32_t)(first % s2);
-        const uint32_t off = rem0 + threadIdx.x;
-        const uint64_t g = first + threadIdx.x;
-        bool active = g < total;
-        const uint64_t seg = active ? seg0 + off / s2 : ~0ull;
+        const uint32_t chunk = (uint32_t)(first / RT_BLOCK);
+        const uint32_t seg = chunk * lp.spb + sib;
+        const bool active = sib < lp.spb && seg < nseg;
         bool lit = false, unsure = false;
         if (active) {
-            const uint32_t kk = off % s2;
-            const uint32_t a = kk / s, b = kk % s;
             const SegF hd = bb.seg[seg];
-            if (hd.ncand > RT_CMAX) unsure = true;
+            const uint32_t ncand = hd.meta & 0xffu;
+            const CandF *cl = bb.cand + (uint64_t)seg * RT_CMAX;
+            CandF k0 = cl[0];                       // issued together with the header: one round trip for most rays
+            if (ncand > RT_CMAX) unsure = true;
             else {
-                float j1[3] = {0, 0, 0}, j2[3] = {0, 0, 0};
+                float j10 = 0, j11 = 0, j12 = 0, j20 = 0, j21 = 0, j22 = 0;
                 if (lp.jitter) {
-                    const uint32_t seg32 = (uint32_t)seg;      // the host enables this kernel only while segments < 2^32
-                    const uint32_t h = seg32 / nsl, ml = seg32 % nsl;
-                    const uint32_t r = hb.list[h];
-                    const uint32_t m = (uint32_t)S.shadow_lights[ml];
-                    const uint32_t pix = q.gpix[r], path = q.path[r];
-                    for (uint32_t stream = 0; stream < 2; ++stream) {
-                        uint32_t x = pix, y = path * 0x9E3779B1u + m, z = lp.seed * 0x85EBCA6Bu + kk * 2u + stream;
-                        pcg3d(x, y, z);
-                        float *j = stream ? j2 : j1;
-                        const float k24 = 1.0f / 16777216.0f;
-                        j[0] = fmaf(2.0f * hd.g, (float)(x >> 8) * k24, -hd.g);
-                        j[1] = fmaf(2.0f * hd.g, (float)(y >> 8) * k24, -hd.g);
-                        j[2] = fmaf(2.0f * hd.g, (float)(z >> 8) * k24, -hd.g);
-                    }
+                    const uint32_t m = hd.meta >> 8;
+                    const float k24 = 1.0f / 16777216.0f, g2 = 2.0f * hd.g;
+                    uint32_t x = hd.pix, y = hd.path * 0x9E3779B1u + m, z = lp.seed * 0x85EBCA6Bu + kk * 2u;
+                    uint32_t x2 = x, y2 = y, z2 = z + 1u;
+                    pcg3d(x, y, z);
+                    pcg3d(x2, y2, z2);
+                    j10 = fmaf(g2, (float)(x >> 8) * k24, -hd.g); j11 = fmaf(g2, (float)(y >> 8) * k24, -hd.g);
+                    j12 = fmaf(g2, (float)(z >> 8) * k24, -hd.g);
+                    j20 = fmaf(g2, (float)(x2 >> 8) * k24, -hd.g); j21 = fmaf(g2, (float)(y2 >> 8) * k24, -hd.g);
+                    j22 = fmaf(g2, (float)(z2 >> 8) * k24, -hd.g);
                 }
                 // w = sample - P (Light.py:273-279), float32
                 const float bg = (float)b * hd.g, ag = (float)a * hd.g;
-                float w0 = hd.q0[0] - bg * hd.up[0] + ag * hd.right[0] + (j1[0] * hd.up[0] + j2[0] * hd.right[0]);
-                float w1 = hd.q0[1] - bg * hd.up[1] + ag * hd.right[1] + (j1[1] * hd.up[1] + j2[1] * hd.right[1]);
-                float w2 = hd.q0[2] - bg * hd.up[2] + ag * hd.right[2] + (j1[2] * hd.up[2] + j2[2] * hd.right[2]);
+                float w0 = hd.q0[0] - bg * hd.up[0] + ag * hd.right[0] + (j10 * hd.up[0] + j20 * hd.right[0]);
+                float w1 = hd.q0[1] - bg * hd.up[1] + ag * hd.right[1] + (j11 * hd.up[1] + j21 * hd.right[1]);
+                float w2 = hd.q0[2] - bg * hd.up[2] + ag * hd.right[2] + (j12 * hd.up[2] + j22 * hd.right[2]);
                 const float nv = sqrtf(fmaf(w0, w0, fmaf(w1, w1, w2 * w2)));
                 const float inv_nv = 1.0f / nv;
                 w0 *= inv_nv; w1 *= inv_nv; w2 *= inv_nv;
@@ -479,15 +527,17 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
                 int n_atp = 0;
                 bool occl = false;
                 if (!(nv > 1e-4f) || !(nv < 1e7f)) unsure = true;
-                for (int k = 0; k < S.n_planes; ++k) {
-                    int v = sh_plane(S.planes[k], hd.pd[k], w0, w1, w2, nv);
-                    occl = occl || v == SH_OCCLUDE;
-                    unsure = unsure || v == SH_UNSURE;
-                    n_atp += v == SH_ATP;
+#pragma unroll
+                for (int k = 0; k < RT_PMAX; ++k) {
+                    if (k < S.n_planes) {
+                        int v = sh_plane(pn[k][0], pn[k][1], pn[k][2], hd.pd[k], w0, w1, w2, nv);
+                        occl = occl || v == SH_OCCLUDE;
+                        unsure = unsure || v == SH_UNSURE;
+                        n_atp += v == SH_ATP;
+                    }
                 }
-                const CandF *cl = bb.cand + seg * RT_CMAX;
-                for (uint32_t c = 0; c < hd.ncand && !occl; ++c) {
-                    const CandF k = cl[c];
+                for (uint32_t c = 0; c < ncand && !occl; ++c) {
+                    const CandF k = c == 0 ? k0 : cl[c];
                     int v = (k.kind & 3u) == 1u ? sh_sphere(k, w0, w1, w2, nv) : sh_box(k, w0, w1, w2, i0, i1, i2, nv);
                     occl = occl || v == SH_OCCLUDE;
                     unsure = unsure || v == SH_UNSURE;
@@ -506,11 +556,11 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
             base = __shfl(base, leader);
             if (unsure) {
                 uint32_t at = base + (uint32_t)__popcll(um & ((1ull << lane) - 1ull));
-                if (at < bb.queue_n[1]) bb.queue[at] = g;
+                if (at < bb.queue_n[1]) bb.queue[at] = (unsigned long long)seg * s2 + kk;
                 else ctl->overflow = 1;             // frame is void; the host re-renders with a larger queue
             }
         }
-        add_lit_counts(hb.lit, active, lit, seg, lane);
+        add_lit_counts(hb.lit, active, lit, active ? (uint64_t)seg : ~0ull, lane);
     }
 }
 
@@ -528,7 +578,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_queue(DScene S, FastScene F
         uint64_t i = first + threadIdx.x;
         if (i >= n) continue;
         const uint64_t g = bb.queue[i];
-        if (shadow_ray_lit<true>(S, F, stk, lp, q, hb, sg, g)) atomicAdd(&hb.lit[g / s2], 1u);
+        if (shadow_ray_lit<true, false>(S, F, stk, lp, q, hb, sg, g)) atomicAdd(&hb.lit[g / s2], 1u);
     }
 }
 
@@ -1014,7 +1064,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
             HIP_C(hipFuncSetAttribute((const void *)&k_intersect<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow_queue, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-            HIP_C(hipFuncSetAttribute((const void *)&k_shadow_setup<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup, hipFuncAttributeMaxDynamicSharedMemorySize, big));
             HIP_C(hipFuncSetAttribute((const void *)&k_intersect_only<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         }
         if (getenv("RT_AMD_DEBUG")) fprintf(stderr, "[rt_amd] kd view: ok=%d depth=%d lds=%zu B\n", ctx->F.ok, max_depth, ctx->lds_bytes);
@@ -1223,8 +1273,14 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
     dim3 grid(ctx->grid), block(RT_BLOCK);
     const bool prof = (p->flags & RT_FLAG_PROFILE) != 0;
     const bool fast = ctx->F.ok && !(p->flags & RT_FLAG_EXACT_TRAVERSAL);
-    const bool beam = fast && ctx->S.n_planes <= RT_PMAX && !(p->flags & RT_FLAG_NO_BEAM) &&
+    const uint32_t s2 = (uint32_t)(sh * sh);
+    const bool beam = fast && ctx->S.n_planes <= RT_PMAX && !(p->flags & RT_FLAG_NO_BEAM) && s2 <= RT_BLOCK &&
                       ctx->cap * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1) < 0xFFFFFFFFull;
+    if (s2 > 0 && s2 <= RT_BLOCK) {
+        lp.spb = RT_BLOCK / s2;
+        lp.magic_s2 = (uint32_t)((0x100000000ull + s2 - 1) / s2);
+        lp.magic_s = (uint32_t)((0x100000000ull + (uint32_t)sh - 1) / (uint32_t)sh);
+    }
     for (int level = 0; level <= rec; ++level) {
         lp.level = level;
         lp.last_level = (level == rec) ? 1 : 0;
@@ -1238,11 +1294,11 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         if (ctx->S.n_shadow_lights > 0) {
             if (beam) {
                 HIP_TRY(ctx, hipMemsetAsync(ctx->beam.queue_n, 0, sizeof(uint32_t), st));
-                hipLaunchKernelGGL(k_shadow_setup<true>, grid, block, ctx->lds_bytes * 3 / 2, st, ctx->S, ctx->F, lp, ctx->hb, ctx->seg, ctx->beam, ctx->ctl);
-                hipLaunchKernelGGL(k_shadow_beam, grid, block, 0, st, ctx->S, lp, qc, ctx->hb, ctx->beam, ctx->ctl);
+                hipLaunchKernelGGL(k_beam_setup, grid, block, ctx->lds_bytes * 3 / 2, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->beam, ctx->ctl);
+                hipLaunchKernelGGL(k_shadow_beam, grid, block, 0, st, ctx->S, lp, ctx->hb, ctx->beam, ctx->ctl);
                 hipLaunchKernelGGL(k_shadow_queue, grid, block, ctx->lds_bytes, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->seg, ctx->beam, ctx->ctl);
             } else {
-                hipLaunchKernelGGL(k_shadow_setup<false>, grid, block, 0, st, ctx->S, ctx->F, lp, ctx->hb, ctx->seg, ctx->beam, ctx->ctl);
+                hipLaunchKernelGGL(k_shadow_setup, grid, block, 0, st, ctx->S, lp, ctx->hb, ctx->seg, ctx->ctl);
                 if (fast) hipLaunchKernelGGL(k_shadow<true>, grid, block, ctx->lds_bytes, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->seg, ctx->ctl);
                 else hipLaunchKernelGGL(k_shadow<false>, grid, block, 0, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->seg, ctx->ctl);
             }

@@ -22,7 +22,7 @@
 #include "rt_fast.hpp"
 
 #define RT_CMAX 8            // candidate primitives kept per (hit, light) pair
-#define RT_PMAX 4            // planes handled by the filtered path
+#define RT_PMAX 3            // planes handled by the filtered path
 
 struct CandF {               // 32 B, coordinates relative to P
     float a[3];              // sphere: centre - P                      box: lo - P rounded down
@@ -31,13 +31,14 @@ struct CandF {               // 32 B, coordinates relative to P
     uint32_t kind;           // 1 sphere, 2 box
 };
 struct SegF {                // 64 B header per (hit, light) pair
-    float q0[3];             // p00 - P  (Light.py:260), from float64
+    float q0[3];             // p00 - P  (Light.py:260)
     float g;                 // radius / s
     float up[3];
-    uint32_t ncand;          // RT_CMAX + 1 = overflow: every ray of the pair goes to the queue
+    uint32_t meta;           // candidates (RT_CMAX + 1 = overflow: every ray of the pair goes to the queue) | light << 8
     float right[3];
-    float pad;
+    uint32_t pix;            // jitter-hash key of the ray that produced the hit
     float pd[RT_PMAX];       // plane k: n_k . P + d_k (from float64; ~1e-16 on P's own plane)
+    uint32_t path;
 };
 struct BeamBuf {
     SegF *seg;
@@ -47,7 +48,7 @@ struct BeamBuf {
 };
 
 #define RT_T1 1e-6f          // the reference's EPSILON (Light.py:221)
-#define RT_RHO 1.9073486e-06f   // 2^-19: relative margin on every tau (direction error 2^-20 + arithmetic)
+#define RT_RHO 1.9073486e-06f   // 2^-19: bound on the ABSOLUTE error of the float32 unit direction w (measured need ~5e-7)
 
 enum { SH_MISS = 0, SH_ATP = 1, SH_OCCLUDE = 2, SH_UNSURE = 3 };
 
@@ -62,8 +63,8 @@ __device__ __forceinline__ int sh_classify(float lo, float hi, float nv) {
 
 __device__ __forceinline__ int sh_sphere(const CandF &k, float w0, float w1, float w2, float nv) {
     const float b = fmaf(w0, k.a[0], fmaf(w1, k.a[1], w2 * k.a[2]));
-    const float eb = 1.5f * RT_RHO * (fabsf(w0 * k.a[0]) + fabsf(w1 * k.a[1]) + fabsf(w2 * k.a[2])) +
-                     RT_RHO * 0.5f * (fabsf(k.a[0]) + fabsf(k.a[1]) + fabsf(k.a[2]));
+    const float eb = RT_2M20 * (fabsf(w0 * k.a[0]) + fabsf(w1 * k.a[1]) + fabsf(w2 * k.a[2])) +
+                     RT_RHO * (fabsf(k.a[0]) + fabsf(k.a[1]) + fabsf(k.a[2]));
     const float disc = fmaf(b, b, -k.c);
     const float ed = fmaf(2.0f * fabsf(b), eb, eb * eb) + 4.8e-7f * (b * b + fabsf(k.c));
     if (disc < -ed) return SH_MISS;                                 // the line misses the sphere
@@ -90,9 +91,9 @@ __device__ __forceinline__ int sh_box(const CandF &k, float w0, float w1, float 
     if (fabsf(w0) < 4e-6f || fabsf(w1) < 4e-6f || fabsf(w2) < 4e-6f) return SH_UNSURE;   // nearly axis parallel
     float a0 = k.a[0] * i0, b0 = k.b[0] * i0, a1 = k.a[1] * i1, b1 = k.b[1] * i1, a2 = k.a[2] * i2, b2 = k.b[2] * i2;
     float n0 = fminf(a0, b0), x0 = fmaxf(a0, b0), n1 = fminf(a1, b1), x1 = fmaxf(a1, b1), n2 = fminf(a2, b2), x2 = fmaxf(a2, b2);
-    // the direction error is ABSOLUTE (<= 2^-20 per component), so the relative error of a slab distance
-    // along axis k is 2^-20 / |w_k| (+ arithmetic)
-    const float r0 = fmaf(RT_2M20, fabsf(i0), RT_2M20), r1 = fmaf(RT_2M20, fabsf(i1), RT_2M20), r2 = fmaf(RT_2M20, fabsf(i2), RT_2M20);
+    // the direction error is ABSOLUTE (<= RT_RHO per component), so the relative error of a slab distance
+    // along axis k is RT_RHO / |w_k| (+ arithmetic)
+    const float r0 = fmaf(RT_RHO, fabsf(i0), RT_2M20), r1 = fmaf(RT_RHO, fabsf(i1), RT_2M20), r2 = fmaf(RT_RHO, fabsf(i2), RT_2M20);
     float en_lo = fmaxf(fmaxf(n0 - fabsf(n0) * r0, n1 - fabsf(n1) * r1), n2 - fabsf(n2) * r2);
     float en_hi = fmaxf(fmaxf(n0 + fabsf(n0) * r0, n1 + fabsf(n1) * r1), n2 + fabsf(n2) * r2);
     float ex_lo = fminf(fminf(x0 - fabsf(x0) * r0, x1 - fabsf(x1) * r1), x2 - fabsf(x2) * r2);
@@ -102,10 +103,9 @@ __device__ __forceinline__ int sh_box(const CandF &k, float w0, float w1, float 
     return sh_classify(ex_lo, ex_hi, nv);                           // the light ray enters at tau = exit
 }
 
-__device__ __forceinline__ int sh_plane(const DPlane &pl, float pd, float w0, float w1, float w2, float nv) {
-    const float n0 = (float)pl.n[0], n1 = (float)pl.n[1], n2 = (float)pl.n[2];
+__device__ __forceinline__ int sh_plane(float n0, float n1, float n2, float pd, float w0, float w1, float w2, float nv) {
     const float vn = fmaf(w0, n0, fmaf(w1, n1, w2 * n2));
-    const float ev = 2.0f * RT_RHO;
+    const float ev = 2.5f * RT_RHO;                                 // |n|_1 <= 1.74, plus the rounding of n and the dot product
     if (vn < -ev) return SH_MISS;                                   // the light ray sees the back: one-sided (InfinitePlane.py:83)
     if (!(vn > ev)) return SH_UNSURE;
     // tau = -pd / vn
@@ -135,22 +135,23 @@ struct BeamStack {           // LDS columns, one entry per tree level
     float *b;                // lambda1
 };
 
-// returns the number of candidates written (RT_CMAX + 1 on overflow)
+__device__ __forceinline__ float sel3(uint32_t ax, float v0, float v1, float v2) { return ax == 0 ? v0 : (ax == 1 ? v1 : v2); }
+
+// returns the number of candidates written (RT_CMAX + 1 on overflow).  c* / h*: centre and half size of the box
+// of all sample origins, relative to P.
 template <int STRIDE>
-__device__ __forceinline__ uint32_t beam_collect(const DScene &S, const FastScene &F, BeamStack stk, d3 P, const float cB[3],
-                                                 const float h[3], CandF *out) {
-    const float Pf[3] = {(float)P.x, (float)P.y, (float)P.z};
-    const float Pl[3] = {(float)(P.x - (double)Pf[0]), (float)(P.y - (double)Pf[1]), (float)(P.z - (double)Pf[2])};
-    const float Kp = fmaxf(fmaxf(fabsf(Pf[0]), fabsf(Pf[1])), fmaxf(fabsf(Pf[2]), F.extent));
+__device__ __forceinline__ uint32_t beam_collect(const DScene &S, const FastScene &F, BeamStack stk, d3 P, float cB0, float cB1,
+                                                 float cB2, float h0, float h1, float h2, CandF *out) {
+    const float Pf0 = (float)P.x, Pf1 = (float)P.y, Pf2 = (float)P.z;
+    const float Pl0 = (float)(P.x - (double)Pf0), Pl1 = (float)(P.y - (double)Pf1), Pl2 = (float)(P.z - (double)Pf2);
+    const float Kp = fmaxf(fmaxf(fabsf(Pf0), fabsf(Pf1)), fmaxf(fabsf(Pf2), F.extent));
     const float E = Kp * RT_2M19 + 2e-6f;            // absolute slack on every plane position (rounding of cut, P, and 1e-6 offsets)
-    float L[3], U[3];
-    for (int k = 0; k < 3; ++k) { L[k] = cB[k] - h[k]; U[k] = cB[k] + h[k]; }
+    const float L0 = cB0 - h0, L1 = cB1 - h1, L2 = cB2 - h2, U0 = cB0 + h0, U1 = cB1 + h1, U2 = cB2 + h2;
     float l0 = 0.0f, l1 = 1.0f;
-    for (int k = 0; k < 3; ++k) {                    // root box relative to P
-        const float rlo = (F.root_lo[k] - Pf[k]) - Pl[k] - E, rhi = (F.root_hi[k] - Pf[k]) - Pl[k] + E;
-        clip_ge(l0, l1, U[k], rlo);
-        clip_le(l0, l1, L[k], rhi);
-    }
+    // root box relative to P
+    clip_ge(l0, l1, U0, (F.root_lo[0] - Pf0) - Pl0 - E); clip_le(l0, l1, L0, (F.root_hi[0] - Pf0) - Pl0 + E);
+    clip_ge(l0, l1, U1, (F.root_lo[1] - Pf1) - Pl1 - E); clip_le(l0, l1, L1, (F.root_hi[1] - Pf1) - Pl1 + E);
+    clip_ge(l0, l1, U2, (F.root_lo[2] - Pf2) - Pl2 - E); clip_le(l0, l1, L2, (F.root_hi[2] - Pf2) - Pl2 + E);
     uint32_t n = 0;
     if (!(l0 <= l1)) return 0;
     uint32_t node = 0;
@@ -160,10 +161,10 @@ __device__ __forceinline__ uint32_t beam_collect(const DScene &S, const FastScen
         bool dead = false;
         while ((nd.b & 3u) != 3u) {
             const uint32_t ax = nd.b & 3u;
-            const float cut = (__uint_as_float(nd.a) - Pf[ax]) - Pl[ax];
+            const float cut = (__uint_as_float(nd.a) - sel3(ax, Pf0, Pf1, Pf2)) - sel3(ax, Pl0, Pl1, Pl2);
             float a0 = l0, a1 = l1, b0 = l0, b1 = l1;
-            clip_le(a0, a1, L[ax], cut + E);         // left child: some beam point with x <= cut
-            clip_ge(b0, b1, U[ax], cut - E);         // right child
+            clip_le(a0, a1, sel3(ax, L0, L1, L2), cut + E);      // left child: some beam point with x <= cut
+            clip_ge(b0, b1, sel3(ax, U0, U1, U2), cut - E);      // right child
             const bool goL = a0 <= a1, goR = b0 <= b1;
             if (goL && goR) {
                 stk.a[sp * STRIDE] = make_uint2(nd.b >> 2, __float_as_uint(b0));
@@ -178,26 +179,23 @@ __device__ __forceinline__ uint32_t beam_collect(const DScene &S, const FastScen
         if (!dead) {
             // beam bounding box over this leaf's lambda range (slightly widened)
             const float m0 = fmaxf(l0 - 1e-6f, 0.0f), m1 = fminf(l1 + 1e-6f, 1.0f);
-            float blo[3], bhi[3];
-            for (int k = 0; k < 3; ++k) {
-                blo[k] = fminf(m0 * L[k], m1 * L[k]) - E;
-                bhi[k] = fmaxf(m0 * U[k], m1 * U[k]) + E;
-            }
+            const float blo0 = fminf(m0 * L0, m1 * L0) - E, bhi0 = fmaxf(m0 * U0, m1 * U0) + E;
+            const float blo1 = fminf(m0 * L1, m1 * L1) - E, bhi1 = fmaxf(m0 * U1, m1 * U1) + E;
+            const float blo2 = fminf(m0 * L2, m1 * L2) - E, bhi2 = fmaxf(m0 * U2, m1 * U2) + E;
             const uint32_t first = nd.a, cnt = nd.b >> 2;
             for (uint32_t e = first; e < first + cnt; ++e) {
                 const LeafF lf = F.leaves[e];
                 const uint32_t kind = lf.pk & 3u, prim = lf.pk >> 2;
-                float plo[3], phi[3];
+                float plo0, plo1, plo2, phi0, phi1, phi2;
                 if (kind == 1u) {
-                    const float c0 = (lf.x - Pf[0]) + (lf.lx - Pl[0]), c1 = (lf.y - Pf[1]) + (lf.ly - Pl[1]), c2 = (lf.z - Pf[2]) + (lf.lz - Pl[2]);
-                    plo[0] = c0 - lf.r; plo[1] = c1 - lf.r; plo[2] = c2 - lf.r;
-                    phi[0] = c0 + lf.r; phi[1] = c1 + lf.r; phi[2] = c2 + lf.r;
+                    const float c0 = (lf.x - Pf0) + (lf.lx - Pl0), c1 = (lf.y - Pf1) + (lf.ly - Pl1), c2 = (lf.z - Pf2) + (lf.lz - Pl2);
+                    plo0 = c0 - lf.r; plo1 = c1 - lf.r; plo2 = c2 - lf.r;
+                    phi0 = c0 + lf.r; phi1 = c1 + lf.r; phi2 = c2 + lf.r;
                 } else {
-                    plo[0] = (lf.x - Pf[0]) - Pl[0]; plo[1] = (lf.y - Pf[1]) - Pl[1]; plo[2] = (lf.z - Pf[2]) - Pl[2];
-                    phi[0] = (lf.lx - Pf[0]) - Pl[0]; phi[1] = (lf.ly - Pf[1]) - Pl[1]; phi[2] = (lf.lz - Pf[2]) - Pl[2];
+                    plo0 = (lf.x - Pf0) - Pl0; plo1 = (lf.y - Pf1) - Pl1; plo2 = (lf.z - Pf2) - Pl2;
+                    phi0 = (lf.lx - Pf0) - Pl0; phi1 = (lf.ly - Pf1) - Pl1; phi2 = (lf.lz - Pf2) - Pl2;
                 }
-                bool touch = true;
-                for (int k = 0; k < 3; ++k) touch = touch && !(plo[k] > bhi[k]) && !(phi[k] < blo[k]);
+                const bool touch = !(plo0 > bhi0) && !(phi0 < blo0) && !(plo1 > bhi1) && !(phi1 < blo1) && !(plo2 > bhi2) && !(phi2 < blo2);
                 if (!touch) continue;
                 bool seen = false;                   // the same primitive is listed in several leaves
                 for (uint32_t j = 0; j < n; ++j) seen = seen || (out[j].kind >> 2) == prim;
