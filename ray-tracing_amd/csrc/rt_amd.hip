@@ -341,9 +341,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_beam_setup(DScene S, FastScene F, 
         const d3 P = mk3(hb.px[r], hb.py[r], hb.pz[r]);
         const DLight &Lt = S.lights[m];
         const d3 dl = ld3(Lt.pos) - P;
-        SegF hd;
-        hd.pix = q.gpix[r];
-        hd.path = q.path[r];
+        float4 *rec = bb.rec + (uint64_t)seg * RT_PAIR_UNITS;
         // D = -(light - P)/|light - P|  (Light.py:81: light_direction = -L)
         const float e0 = (float)dl.x, e1 = (float)dl.y, e2 = (float)dl.z;
         const float il = 1.0f / sqrtf(fmaf(e0, e0, fmaf(e1, e1, e2 * e2)));
@@ -362,34 +360,35 @@ __global__ void __launch_bounds__(RT_BLOCK) k_beam_setup(DScene S, FastScene F, 
         const float ir = 1.0f / (sqrtf(fmaf(r0, r0, fmaf(r1, r1, r2 * r2))) + 1e-6f);
         r0 *= ir; r1 *= ir; r2 *= ir;
         const float radius = (float)Lt.radius;
-        hd.g = radius / (float)lp.sh_rays;
-        const float c0 = (radius - hd.g) * 0.5f;
-        hd.q0[0] = e0 + c0 * (u0 - r0); hd.q0[1] = e1 + c0 * (u1 - r1); hd.q0[2] = e2 + c0 * (u2 - r2);
-        hd.up[0] = u0; hd.up[1] = u1; hd.up[2] = u2;
-        hd.right[0] = r0; hd.right[1] = r1; hd.right[2] = r2;
+        const float g = radius / (float)lp.sh_rays;
+        const float c0 = (radius - g) * 0.5f;
+        const float q00 = e0 + c0 * (u0 - r0), q01 = e1 + c0 * (u1 - r1), q02 = e2 + c0 * (u2 - r2);
+        float pd[RT_PMAX];
 #pragma unroll
         for (int k = 0; k < RT_PMAX; ++k) {
             float v = 0.0f;
             if (k < S.n_planes) v = (float)(dot3(ld3(S.planes[k].n), P) + S.planes[k].d);
-            hd.pd[k] = v;
+            pd[k] = v;
         }
+        rec[0] = make_float4(q00, q01, q02, g);
+        rec[2] = make_float4(r0, r1, r2, __uint_as_float(q.gpix[r]));
+        rec[3] = make_float4(pd[0], pd[1], pd[2], __uint_as_float(q.path[r]));
         // box of every sample origin of the pair, relative to P: grid points a,b in [0,s-1] and the
         // component-wise deviations of Light.py:277-279 (|u| <= g on each of up and right)
         const float sm1 = (float)(lp.sh_rays - 1);
-        const float cB0 = hd.q0[0] + 0.5f * sm1 * hd.g * (r0 - u0), cB1 = hd.q0[1] + 0.5f * sm1 * hd.g * (r1 - u1),
-                    cB2 = hd.q0[2] + 0.5f * sm1 * hd.g * (r2 - u2);
-        float h0 = (0.5f * sm1 + 1.0f) * hd.g * (fabsf(u0) + fabsf(r0)), h1 = (0.5f * sm1 + 1.0f) * hd.g * (fabsf(u1) + fabsf(r1)),
-              h2 = (0.5f * sm1 + 1.0f) * hd.g * (fabsf(u2) + fabsf(r2));
+        const float cB0 = q00 + 0.5f * sm1 * g * (r0 - u0), cB1 = q01 + 0.5f * sm1 * g * (r1 - u1), cB2 = q02 + 0.5f * sm1 * g * (r2 - u2);
+        float h0 = (0.5f * sm1 + 1.0f) * g * (fabsf(u0) + fabsf(r0)), h1 = (0.5f * sm1 + 1.0f) * g * (fabsf(u1) + fabsf(r1)),
+              h2 = (0.5f * sm1 + 1.0f) * g * (fabsf(u2) + fabsf(r2));
         h0 = fmaf(RT_2M18, fabsf(cB0) + h0, h0) + 1e-5f;
         h1 = fmaf(RT_2M18, fabsf(cB1) + h1, h1) + 1e-5f;
         h2 = fmaf(RT_2M18, fabsf(cB2) + h2, h2) + 1e-5f;
         BeamStack bs;
         bs.a = lds_stack + threadIdx.x;
         bs.b = (float *)(lds_stack + (size_t)F.depth * RT_BLOCK) + threadIdx.x;
-        uint32_t nc = RT_CMAX + 1;
-        if (!delicate) nc = beam_collect<RT_BLOCK>(S, F, bs, P, cB0, cB1, cB2, h0, h1, h2, bb.cand + (uint64_t)seg * RT_CMAX);
-        hd.meta = nc | ((uint32_t)m << 8);
-        bb.seg[seg] = hd;
+        uint32_t nc = RT_META_OVERFLOW;
+        if (!delicate && (lp.flags & 0x100)) nc = 0;   // timing experiment only
+        else if (!delicate) nc = beam_collect<RT_BLOCK>(S, F, bs, P, cB0, cB1, cB2, h0, h1, h2, rec + 4);
+        rec[1] = make_float4(u0, u1, u2, __uint_as_float(nc | ((uint32_t)m << 16)));
     }
 }
 
@@ -474,13 +473,19 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene S, FastScene F, Leve
 }
 
 // one lane per soft-shadow ray, float32 filtered predicates on the pair's candidate list (rt_shadow.hpp);
-// undecided rays go to the queue.  A chunk of RT_BLOCK lanes holds lp.spb whole pairs.
+// undecided rays go to the queue.  A chunk of RT_BLOCK lanes holds lp.spb whole pairs; their records
+// (lp.spb * 192 contiguous bytes) are staged through LDS with one coalesced 16-byte load per lane, issued one
+// chunk ahead and parked in registers while the current chunk is classified - the HBM round trip of a chunk
+// overlaps the arithmetic of the previous one.
+#define RT_STAGE 3     // 16-byte units a lane stages per chunk: covers lp.spb * 12 <= 768 units (s*s >= 4)
 __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams lp, HitBuf hb, BeamBuf bb, FrameCtl *ctl) {
+    extern __shared__ float4 pair_lds[];
     if (ctl->overflow) return;
     const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
     const uint32_t s = (uint32_t)lp.sh_rays, s2 = s * s;
     const uint32_t nseg = n_hits * (uint32_t)S.n_shadow_lights;
     const uint32_t nchunks = (nseg + lp.spb - 1) / lp.spb;
+    const uint32_t units = lp.spb * RT_PAIR_UNITS;
     ChunkWalk walk((uint64_t)nchunks * RT_BLOCK);
     uint64_t first;
     const int lane = threadIdx.x & 63;
@@ -490,36 +495,56 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
     float pn[RT_PMAX][3];
     for (int k = 0; k < RT_PMAX; ++k)
         for (int c = 0; c < 3; ++c) pn[k][c] = k < S.n_planes ? (float)S.planes[k].n[c] : 0.0f;
-    while (walk.next(first)) {
-        const uint32_t chunk = (uint32_t)(first / RT_BLOCK);
-        const uint32_t seg = chunk * lp.spb + sib;
+    float4 st0 = make_float4(0, 0, 0, 0), st1 = st0, st2 = st0;
+    const uint32_t i0u = threadIdx.x, i1u = threadIdx.x + RT_BLOCK, i2u = threadIdx.x + 2 * RT_BLOCK;
+#define RT_STAGE_LOAD(src_) do { if (i0u < units) st0 = (src_)[i0u]; if (i1u < units) st1 = (src_)[i1u]; if (i2u < units) st2 = (src_)[i2u]; } while (0)
+    bool have = walk.next(first);
+    uint32_t chunk = have ? (uint32_t)(first / RT_BLOCK) : 0u;
+    if (have) {
+        const float4 *src = bb.rec + (uint64_t)chunk * units;
+        RT_STAGE_LOAD(src);
+    }
+    while (have) {
+        if (i0u < units) pair_lds[i0u] = st0;
+        if (i1u < units) pair_lds[i1u] = st1;
+        if (i2u < units) pair_lds[i2u] = st2;
+        __syncthreads();
+        const uint32_t cur = chunk;
+        have = walk.next(first);
+        if (have) {                                  // next chunk's records: in flight during the arithmetic below
+            chunk = (uint32_t)(first / RT_BLOCK);
+            const float4 *src = bb.rec + (uint64_t)chunk * units;
+            RT_STAGE_LOAD(src);
+        }
+        const uint32_t seg = cur * lp.spb + sib;
         const bool active = sib < lp.spb && seg < nseg;
         bool lit = false, unsure = false;
         if (active) {
-            const SegF hd = bb.seg[seg];
-            const uint32_t ncand = hd.meta & 0xffu;
-            const CandF *cl = bb.cand + (uint64_t)seg * RT_CMAX;
-            CandF k0 = cl[0];                       // issued together with the header: one round trip for most rays
-            if (ncand > RT_CMAX) unsure = true;
+            const float4 *rec = pair_lds + sib * RT_PAIR_UNITS;
+            const float4 h0 = rec[0], h1 = rec[1], h2 = rec[2], h3 = rec[3];
+            const float g = h0.w;
+            const uint32_t meta = __float_as_uint(h1.w);
+            const uint32_t nu = meta & 0xffu, boxmask = (meta >> 8) & 0xffu;
+            if (nu == RT_META_OVERFLOW) unsure = true;
             else {
                 float j10 = 0, j11 = 0, j12 = 0, j20 = 0, j21 = 0, j22 = 0;
                 if (lp.jitter) {
-                    const uint32_t m = hd.meta >> 8;
-                    const float k24 = 1.0f / 16777216.0f, g2 = 2.0f * hd.g;
-                    uint32_t x = hd.pix, y = hd.path * 0x9E3779B1u + m, z = lp.seed * 0x85EBCA6Bu + kk * 2u;
+                    const uint32_t m = meta >> 16;
+                    const float k24 = 1.0f / 16777216.0f, g2 = 2.0f * g;
+                    uint32_t x = __float_as_uint(h2.w), y = __float_as_uint(h3.w) * 0x9E3779B1u + m, z = lp.seed * 0x85EBCA6Bu + kk * 2u;
                     uint32_t x2 = x, y2 = y, z2 = z + 1u;
                     pcg3d(x, y, z);
                     pcg3d(x2, y2, z2);
-                    j10 = fmaf(g2, (float)(x >> 8) * k24, -hd.g); j11 = fmaf(g2, (float)(y >> 8) * k24, -hd.g);
-                    j12 = fmaf(g2, (float)(z >> 8) * k24, -hd.g);
-                    j20 = fmaf(g2, (float)(x2 >> 8) * k24, -hd.g); j21 = fmaf(g2, (float)(y2 >> 8) * k24, -hd.g);
-                    j22 = fmaf(g2, (float)(z2 >> 8) * k24, -hd.g);
+                    j10 = fmaf(g2, (float)(x >> 8) * k24, -g); j11 = fmaf(g2, (float)(y >> 8) * k24, -g);
+                    j12 = fmaf(g2, (float)(z >> 8) * k24, -g);
+                    j20 = fmaf(g2, (float)(x2 >> 8) * k24, -g); j21 = fmaf(g2, (float)(y2 >> 8) * k24, -g);
+                    j22 = fmaf(g2, (float)(z2 >> 8) * k24, -g);
                 }
                 // w = sample - P (Light.py:273-279), float32
-                const float bg = (float)b * hd.g, ag = (float)a * hd.g;
-                float w0 = hd.q0[0] - bg * hd.up[0] + ag * hd.right[0] + (j10 * hd.up[0] + j20 * hd.right[0]);
-                float w1 = hd.q0[1] - bg * hd.up[1] + ag * hd.right[1] + (j11 * hd.up[1] + j21 * hd.right[1]);
-                float w2 = hd.q0[2] - bg * hd.up[2] + ag * hd.right[2] + (j12 * hd.up[2] + j22 * hd.right[2]);
+                const float bg = (float)b * g, ag = (float)a * g;
+                float w0 = h0.x - bg * h1.x + ag * h2.x + (j10 * h1.x + j20 * h2.x);
+                float w1 = h0.y - bg * h1.y + ag * h2.y + (j11 * h1.y + j21 * h2.y);
+                float w2 = h0.z - bg * h1.z + ag * h2.z + (j12 * h1.z + j22 * h2.z);
                 const float nv = sqrtf(fmaf(w0, w0, fmaf(w1, w1, w2 * w2)));
                 const float inv_nv = 1.0f / nv;
                 w0 *= inv_nv; w1 *= inv_nv; w2 *= inv_nv;
@@ -527,18 +552,30 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
                 int n_atp = 0;
                 bool occl = false;
                 if (!(nv > 1e-4f) || !(nv < 1e7f)) unsure = true;
+                const float pdk[RT_PMAX] = {h3.x, h3.y, h3.z};
 #pragma unroll
                 for (int k = 0; k < RT_PMAX; ++k) {
                     if (k < S.n_planes) {
-                        int v = sh_plane(pn[k][0], pn[k][1], pn[k][2], hd.pd[k], w0, w1, w2, nv);
+                        int v = sh_plane(pn[k][0], pn[k][1], pn[k][2], pdk[k], w0, w1, w2, nv);
                         occl = occl || v == SH_OCCLUDE;
                         unsure = unsure || v == SH_UNSURE;
                         n_atp += v == SH_ATP;
                     }
                 }
-                for (uint32_t c = 0; c < ncand && !occl; ++c) {
-                    const CandF k = c == 0 ? k0 : cl[c];
-                    int v = (k.kind & 3u) == 1u ? sh_sphere(k, w0, w1, w2, nv) : sh_box(k, w0, w1, w2, i0, i1, i2, nv);
+                for (uint32_t j = 0; j < nu && !occl;) {
+                    const float4 ua = rec[4 + j];
+                    CandF k;
+                    k.a[0] = ua.x; k.a[1] = ua.y; k.a[2] = ua.z; k.c = ua.w;
+                    int v;
+                    if ((boxmask >> j) & 1u) {
+                        const float4 ub = rec[5 + j];
+                        k.b[0] = ua.w; k.b[1] = ub.x; k.b[2] = ub.y;
+                        v = sh_box(k, w0, w1, w2, i0, i1, i2, nv);
+                        j += 2;
+                    } else {
+                        v = sh_sphere(k, w0, w1, w2, nv);
+                        j += 1;
+                    }
                     occl = occl || v == SH_OCCLUDE;
                     unsure = unsure || v == SH_UNSURE;
                     n_atp += v == SH_ATP;
@@ -561,6 +598,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
             }
         }
         add_lit_counts(hb.lit, active, lit, active ? (uint64_t)seg : ~0ull, lane);
+        __syncthreads();                             // everyone is done with pair_lds before it is overwritten
     }
 }
 
@@ -829,6 +867,9 @@ struct rt_ctx {
     int32_t last_sh = 0, last_rec = 0;
     uint64_t last_slots = 0;
     int grid = 2048;
+    int n_cu = 256;
+    int g_intersect = 2048, g_intersect_x = 2048, g_shadow = 2048, g_shadow_x = 2048, g_beam_setup = 2048, g_beam = 2048,
+        g_queue = 2048, g_shade = 2048, g_setup = 2048;
 };
 
 static int fail(rt_ctx *ctx, int code, const std::string &msg) {
@@ -930,6 +971,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
     HIP_C(hipHostMalloc((void **)&ctx->h_ctl, sizeof(FrameCtl), hipHostMallocDefault));
     hipDeviceProp_t prop;
     HIP_C(hipGetDeviceProperties(&prop, device));
+    ctx->n_cu = prop.multiProcessorCount;
     ctx->grid = prop.multiProcessorCount * 8;
     ctx->grid = (ctx->grid + 7) & ~7;
 
@@ -1070,6 +1112,33 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
         if (getenv("RT_AMD_DEBUG")) fprintf(stderr, "[rt_amd] kd view: ok=%d depth=%d lds=%zu B\n", ctx->F.ok, max_depth, ctx->lds_bytes);
     }
 
+    // ---- grid = exactly the workgroups that are resident at once (every kernel walks its queue with a fixed
+    // grid; a second, partially filled round of workgroups would run at a fraction of the occupancy) ----
+    {
+        const char *ov = getenv("RT_AMD_BLOCKS_PER_CU");
+        auto grid_for = [&](const void *fn, size_t lds) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, RT_BLOCK, lds) != hipSuccess || nb < 1) nb = 1;
+            if (nb > 6) nb = 6;       // ~100 SGPRs per wave admit 6 workgroups of 256 per CU (MI355X_MICROARCH.md, residency)
+            if (ov && atoi(ov) > 0) nb = atoi(ov);
+            int g = ctx->n_cu * nb;
+            return (g + 7) & ~7;
+        };
+        const size_t lds = ctx->lds_bytes;
+        ctx->g_intersect = grid_for((const void *)&k_intersect<true>, lds);
+        ctx->g_intersect_x = grid_for((const void *)&k_intersect<false>, 0);
+        ctx->g_shadow = grid_for((const void *)&k_shadow<true>, lds);
+        ctx->g_shadow_x = grid_for((const void *)&k_shadow<false>, 0);
+        ctx->g_beam_setup = grid_for((const void *)&k_beam_setup, lds * 3 / 2);
+        ctx->g_beam = grid_for((const void *)&k_shadow_beam, 12288);
+        ctx->g_queue = grid_for((const void *)&k_shadow_queue, lds);
+        ctx->g_shade = grid_for((const void *)&k_shade, 0);
+        ctx->g_setup = grid_for((const void *)&k_shadow_setup, 0);
+        if (getenv("RT_AMD_DEBUG"))
+            fprintf(stderr, "[rt_amd] grids: intersect %d beam_setup %d beam %d queue %d shade %d\n", ctx->g_intersect,
+                    ctx->g_beam_setup, ctx->g_beam, ctx->g_queue, ctx->g_shade);
+    }
+
     // ---- planes / surfaces / materials / lights ----
     std::vector<DPlane> planes(s->n_planes);
     for (int i = 0; i < s->n_planes; ++i) {
@@ -1181,7 +1250,7 @@ static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
     TRY_A(dalloc(ctx, &sg.cx, nlit)); TRY_A(dalloc(ctx, &sg.cy, nlit)); TRY_A(dalloc(ctx, &sg.cz, nlit));
     BeamBuf &bb = ctx->beam;
     ctx->beam_queue_cap = (uint32_t)(cap < 0x7fffffffull ? cap : 0x7fffffffull);
-    TRY_A(dalloc(ctx, &bb.seg, nlit)); TRY_A(dalloc(ctx, &bb.cand, nlit * RT_CMAX));
+    TRY_A(dalloc(ctx, &bb.rec, (nlit + RT_BLOCK) * RT_PAIR_UNITS));   // + one chunk of slack: staging reads whole chunks
     TRY_A(dalloc(ctx, &bb.queue, (uint64_t)ctx->beam_queue_cap)); TRY_A(dalloc(ctx, &bb.queue_n, 2));
     {
         uint32_t init[2] = {0u, ctx->beam_queue_cap};
@@ -1274,7 +1343,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
     const bool prof = (p->flags & RT_FLAG_PROFILE) != 0;
     const bool fast = ctx->F.ok && !(p->flags & RT_FLAG_EXACT_TRAVERSAL);
     const uint32_t s2 = (uint32_t)(sh * sh);
-    const bool beam = fast && ctx->S.n_planes <= RT_PMAX && !(p->flags & RT_FLAG_NO_BEAM) && s2 <= RT_BLOCK &&
+    const bool beam = fast && ctx->S.n_planes <= RT_PMAX && !(p->flags & RT_FLAG_NO_BEAM) && s2 >= 4 && s2 <= RT_BLOCK &&
                       ctx->cap * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1) < 0xFFFFFFFFull;
     if (s2 > 0 && s2 <= RT_BLOCK) {
         lp.spb = RT_BLOCK / s2;
@@ -1287,25 +1356,25 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         RayQ &qc = ctx->q[level & 1], &qn = ctx->q[(level + 1) & 1];
         const int e = 2 + 6 * level;
         PROF_MARK(e + 0);
-        if (fast) hipLaunchKernelGGL(k_intersect<true>, grid, block, ctx->lds_bytes, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->ctl, ctx->fb, d_ids);
-        else hipLaunchKernelGGL(k_intersect<false>, grid, block, 0, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->ctl, ctx->fb, d_ids);
+        if (fast) hipLaunchKernelGGL(k_intersect<true>, dim3(ctx->g_intersect), block, ctx->lds_bytes, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->ctl, ctx->fb, d_ids);
+        else hipLaunchKernelGGL(k_intersect<false>, dim3(ctx->g_intersect_x), block, 0, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->ctl, ctx->fb, d_ids);
         PROF_MARK(e + 1);
         PROF_MARK(e + 2);
         if (ctx->S.n_shadow_lights > 0) {
             if (beam) {
                 HIP_TRY(ctx, hipMemsetAsync(ctx->beam.queue_n, 0, sizeof(uint32_t), st));
-                hipLaunchKernelGGL(k_beam_setup, grid, block, ctx->lds_bytes * 3 / 2, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->beam, ctx->ctl);
-                hipLaunchKernelGGL(k_shadow_beam, grid, block, 0, st, ctx->S, lp, ctx->hb, ctx->beam, ctx->ctl);
-                hipLaunchKernelGGL(k_shadow_queue, grid, block, ctx->lds_bytes, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->seg, ctx->beam, ctx->ctl);
+                hipLaunchKernelGGL(k_beam_setup, dim3(ctx->g_beam_setup), block, ctx->lds_bytes * 3 / 2, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->beam, ctx->ctl);
+                hipLaunchKernelGGL(k_shadow_beam, dim3(ctx->g_beam), block, (size_t)lp.spb * RT_PAIR_UNITS * sizeof(float4), st, ctx->S, lp, ctx->hb, ctx->beam, ctx->ctl);
+                hipLaunchKernelGGL(k_shadow_queue, dim3(ctx->g_queue), block, ctx->lds_bytes, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->seg, ctx->beam, ctx->ctl);
             } else {
-                hipLaunchKernelGGL(k_shadow_setup, grid, block, 0, st, ctx->S, lp, ctx->hb, ctx->seg, ctx->ctl);
-                if (fast) hipLaunchKernelGGL(k_shadow<true>, grid, block, ctx->lds_bytes, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->seg, ctx->ctl);
-                else hipLaunchKernelGGL(k_shadow<false>, grid, block, 0, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->seg, ctx->ctl);
+                hipLaunchKernelGGL(k_shadow_setup, dim3(ctx->g_setup), block, 0, st, ctx->S, lp, ctx->hb, ctx->seg, ctx->ctl);
+                if (fast) hipLaunchKernelGGL(k_shadow<true>, dim3(ctx->g_shadow), block, ctx->lds_bytes, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->seg, ctx->ctl);
+                else hipLaunchKernelGGL(k_shadow<false>, dim3(ctx->g_shadow_x), block, 0, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->seg, ctx->ctl);
             }
         }
         PROF_MARK(e + 3);
         PROF_MARK(e + 4);
-        hipLaunchKernelGGL(k_shade, grid, block, 0, st, ctx->S, lp, qc, qn, ctx->hb, ctx->ctl, ctx->fb);
+        hipLaunchKernelGGL(k_shade, dim3(ctx->g_shade), block, 0, st, ctx->S, lp, qc, qn, ctx->hb, ctx->ctl, ctx->fb);
         PROF_MARK(e + 5);
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -1407,6 +1476,26 @@ extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
             }
             stats->ms_resolve = span(2 + 6 * ctx->prof_levels);
             stats->launches_per_family = ctx->prof_levels;
+        }
+    }
+    if (getenv("RT_AMD_DEBUG") && ctx->beam.rec && c.n_hits[0] > 0) {
+        // histogram of candidate units over a slice of level-0 pairs (diagnostics only)
+        uint64_t nseg = (uint64_t)c.n_hits[0] * (uint64_t)ctx->S.n_shadow_lights;
+        uint64_t lo = nseg / 2, n = nseg - lo < 500000 ? nseg - lo : 500000;
+        std::vector<float4> h(n * RT_PAIR_UNITS);
+        if (n && hipMemcpy(h.data(), ctx->beam.rec + lo * RT_PAIR_UNITS, h.size() * sizeof(float4), hipMemcpyDeviceToHost) == hipSuccess) {
+            uint64_t hist[RT_CUNITS + 2] = {0};
+            for (uint64_t i = 0; i < n; ++i) {
+                uint32_t meta;
+                memcpy(&meta, &h[i * RT_PAIR_UNITS + 1].w, 4);
+                uint32_t nu = meta & 0xff;
+                hist[nu > RT_CUNITS ? RT_CUNITS + 1 : nu]++;
+            }
+            fprintf(stderr, "[rt_amd] candidate units per pair over %llu pairs:", (unsigned long long)n);
+            for (int k = 0; k <= RT_CUNITS + 1; ++k) fprintf(stderr, " %d:%.1f%%", k, 100.0 * hist[k] / n);
+            uint32_t qn[2] = {0, 0};
+            (void)hipMemcpy(qn, ctx->beam.queue_n, sizeof(qn), hipMemcpyDeviceToHost);
+            fprintf(stderr, "  | queue of the last level: %u\n", qn[0]);
         }
     }
     if (c.overflow) {

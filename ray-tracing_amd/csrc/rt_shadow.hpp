@@ -21,31 +21,31 @@
 #pragma once
 #include "rt_fast.hpp"
 
-#define RT_CMAX 8            // candidate primitives kept per (hit, light) pair
+#define RT_CUNITS 8          // 16-byte candidate units kept per (hit, light) pair: a sphere takes 1, a box 2
+#define RT_CMAX RT_CUNITS
 #define RT_PMAX 3            // planes handled by the filtered path
+#define RT_PAIR_UNITS (4 + RT_CUNITS)   // one pair record = 12 float4 = 192 B, contiguous
 
-struct CandF {               // 32 B, coordinates relative to P
-    float a[3];              // sphere: centre - P                      box: lo - P rounded down
-    float c;                 // sphere: |centre - P|^2 - r^2 (from float64)
-    float b[3];              // box: hi - P rounded up
-    uint32_t kind;           // 1 sphere, 2 box
-};
-struct SegF {                // 64 B header per (hit, light) pair
-    float q0[3];             // p00 - P  (Light.py:260)
-    float g;                 // radius / s
-    float up[3];
-    uint32_t meta;           // candidates (RT_CMAX + 1 = overflow: every ray of the pair goes to the queue) | light << 8
-    float right[3];
-    uint32_t pix;            // jitter-hash key of the ray that produced the hit
-    float pd[RT_PMAX];       // plane k: n_k . P + d_k (from float64; ~1e-16 on P's own plane)
-    uint32_t path;
+// Pair record (float4 units), coordinates relative to P:
+//   u0 = {q0.xyz (p00 - P, Light.py:260), g = radius / s}
+//   u1 = {up.xyz, meta}      meta: bits 0-7 candidate units used (0xFF = overflow: every ray of the pair goes to
+//                                   the queue), bits 8-15 bit j set = unit j starts a box, bits 16-31 light index
+//   u2 = {right.xyz, pix}    pix / path: jitter-hash keys of the ray that produced the hit
+//   u3 = {pd[0..2], path}    plane k: n_k . P + d_k (from float64; ~1e-16 on P's own plane)
+//   u4.. candidates          sphere: {centre - P, |centre - P|^2 - r^2 (float64, then rounded)}
+//                            box:    {lo - P rounded down, hi.x - P.x rounded up}, {hi.y, hi.z rounded up, 0, 0}
+struct CandF {               // decoded candidate
+    float a[3];
+    float c;
+    float b[3];
+    uint32_t kind;
 };
 struct BeamBuf {
-    SegF *seg;
-    CandF *cand;             // [segment][RT_CMAX]
+    float4 *rec;             // [pair][RT_PAIR_UNITS]
     unsigned long long *queue;   // shadow-ray numbers g the filter could not decide
     uint32_t *queue_n;       // [0] = entries appended, [1] = capacity
 };
+#define RT_META_OVERFLOW 0xFFu
 
 #define RT_T1 1e-6f          // the reference's EPSILON (Light.py:221)
 #define RT_RHO 1.9073486e-06f   // 2^-19: bound on the ABSOLUTE error of the float32 unit direction w (measured need ~5e-7)
@@ -137,23 +137,33 @@ struct BeamStack {           // LDS columns, one entry per tree level
 
 __device__ __forceinline__ float sel3(uint32_t ax, float v0, float v1, float v2) { return ax == 0 ? v0 : (ax == 1 ? v1 : v2); }
 
-// returns the number of candidates written (RT_CMAX + 1 on overflow).  c* / h*: centre and half size of the box
-// of all sample origins, relative to P.
+// returns units used | box mask << 8 (RT_META_OVERFLOW when the units do not suffice).  c* / h*: centre and half
+// size of the box of all sample origins, relative to P.  out: the pair record's RT_CUNITS candidate units.
 template <int STRIDE>
 __device__ __forceinline__ uint32_t beam_collect(const DScene &S, const FastScene &F, BeamStack stk, d3 P, float cB0, float cB1,
-                                                 float cB2, float h0, float h1, float h2, CandF *out) {
+                                                 float cB2, float h0, float h1, float h2, float4 *out) {
     const float Pf0 = (float)P.x, Pf1 = (float)P.y, Pf2 = (float)P.z;
     const float Pl0 = (float)(P.x - (double)Pf0), Pl1 = (float)(P.y - (double)Pf1), Pl2 = (float)(P.z - (double)Pf2);
     const float Kp = fmaxf(fmaxf(fabsf(Pf0), fabsf(Pf1)), fmaxf(fabsf(Pf2), F.extent));
     const float E = Kp * RT_2M19 + 2e-6f;            // absolute slack on every plane position (rounding of cut, P, and 1e-6 offsets)
     const float L0 = cB0 - h0, L1 = cB1 - h1, L2 = cB2 - h2, U0 = cB0 + h0, U1 = cB1 + h1, U2 = cB2 + h2;
+    // the beam also lies inside the cone with apex P, axis cB and half-angle tan = |h| / |cB| (used for spheres)
+    const float cl2 = fmaf(cB0, cB0, fmaf(cB1, cB1, cB2 * cB2));
+    const float icl = 1.0f / sqrtf(cl2);
+    const float ax0 = cB0 * icl, ax1 = cB1 * icl, ax2 = cB2 * icl;
+    const float kt = sqrtf(fmaf(h0, h0, fmaf(h1, h1, h2 * h2))) * icl * 1.0001f;      // tan(half angle), rounded up
+    const float ax_len = cl2 * icl;
     float l0 = 0.0f, l1 = 1.0f;
     // root box relative to P
     clip_ge(l0, l1, U0, (F.root_lo[0] - Pf0) - Pl0 - E); clip_le(l0, l1, L0, (F.root_hi[0] - Pf0) - Pl0 + E);
     clip_ge(l0, l1, U1, (F.root_lo[1] - Pf1) - Pl1 - E); clip_le(l0, l1, L1, (F.root_hi[1] - Pf1) - Pl1 + E);
     clip_ge(l0, l1, U2, (F.root_lo[2] - Pf2) - Pl2 - E); clip_le(l0, l1, L2, (F.root_hi[2] - Pf2) - Pl2 + E);
-    uint32_t n = 0;
+    uint32_t n = 0, nu = 0, boxmask = 0;             // candidates, units used, which units start a box
+    uint32_t ids[RT_CMAX];                           // registers (static indices only): the pair's candidates so far
+#pragma unroll
+    for (uint32_t j = 0; j < RT_CMAX; ++j) ids[j] = 0xffffffffu;
     if (!(l0 <= l1)) return 0;
+    (void)n;
     uint32_t node = 0;
     int sp = 0;
     for (;;) {
@@ -187,38 +197,46 @@ __device__ __forceinline__ uint32_t beam_collect(const DScene &S, const FastScen
                 const LeafF lf = F.leaves[e];
                 const uint32_t kind = lf.pk & 3u, prim = lf.pk >> 2;
                 float plo0, plo1, plo2, phi0, phi1, phi2;
+                bool in_cone = true;
                 if (kind == 1u) {
                     const float c0 = (lf.x - Pf0) + (lf.lx - Pl0), c1 = (lf.y - Pf1) + (lf.ly - Pl1), c2 = (lf.z - Pf2) + (lf.lz - Pl2);
                     plo0 = c0 - lf.r; plo1 = c1 - lf.r; plo2 = c2 - lf.r;
                     phi0 = c0 + lf.r; phi1 = c1 + lf.r; phi2 = c2 + lf.r;
+                    // sphere against the cone: distance to the axis <= r (1 + tan) + axial position * tan (conservative)
+                    const float ta = fmaf(c0, ax0, fmaf(c1, ax1, c2 * ax2));
+                    const float cc = fmaf(c0, c0, fmaf(c1, c1, c2 * c2));
+                    const float dp2 = fmaxf(cc - ta * ta, 0.0f);
+                    const float lim = fmaf(lf.r, 1.0f + kt, fmaxf(ta, 0.0f) * kt) + E + 2e-6f * sqrtf(cc);
+                    in_cone = !(dp2 > lim * lim * 1.0001f) && !(ta < -(lf.r + E)) && !(ta > ax_len * (1.0f + kt) + lf.r + E);
                 } else {
                     plo0 = (lf.x - Pf0) - Pl0; plo1 = (lf.y - Pf1) - Pl1; plo2 = (lf.z - Pf2) - Pl2;
                     phi0 = (lf.lx - Pf0) - Pl0; phi1 = (lf.ly - Pf1) - Pl1; phi2 = (lf.lz - Pf2) - Pl2;
                 }
                 const bool touch = !(plo0 > bhi0) && !(phi0 < blo0) && !(plo1 > bhi1) && !(phi1 < blo1) && !(plo2 > bhi2) && !(phi2 < blo2);
-                if (!touch) continue;
+                if (!touch || !in_cone) continue;
                 bool seen = false;                   // the same primitive is listed in several leaves
-                for (uint32_t j = 0; j < n; ++j) seen = seen || (out[j].kind >> 2) == prim;
+#pragma unroll
+                for (uint32_t j = 0; j < RT_CMAX; ++j) seen = seen || (j < n && ids[j] == prim);
                 if (seen) continue;
-                if (n == RT_CMAX) return RT_CMAX + 1;
+                if (nu + kind > RT_CUNITS) return RT_META_OVERFLOW;       // kind == units needed (sphere 1, box 2)
                 const DPrim *pr = S.prims + prim;
-                CandF c;
                 if (kind == 1u) {
                     const double dx = pr->a[0] - P.x, dy = pr->a[1] - P.y, dz = pr->a[2] - P.z;
-                    c.a[0] = (float)dx; c.a[1] = (float)dy; c.a[2] = (float)dz;
-                    c.c = (float)(((dx * dx + dy * dy) + dz * dz) - pr->b[0]);
-                    c.b[0] = c.b[1] = c.b[2] = 0.0f;
+                    out[nu] = make_float4((float)dx, (float)dy, (float)dz, (float)(((dx * dx + dy * dy) + dz * dz) - pr->b[0]));
+                    nu += 1;
                 } else {
-                    c.a[0] = __double2float_rd(pr->a[0] - P.x); c.a[1] = __double2float_rd(pr->a[1] - P.y); c.a[2] = __double2float_rd(pr->a[2] - P.z);
-                    c.b[0] = __double2float_ru(pr->b[0] - P.x); c.b[1] = __double2float_ru(pr->b[1] - P.y); c.b[2] = __double2float_ru(pr->b[2] - P.z);
-                    c.c = 0.0f;
+                    out[nu] = make_float4(__double2float_rd(pr->a[0] - P.x), __double2float_rd(pr->a[1] - P.y),
+                                          __double2float_rd(pr->a[2] - P.z), __double2float_ru(pr->b[0] - P.x));
+                    out[nu + 1] = make_float4(__double2float_ru(pr->b[1] - P.y), __double2float_ru(pr->b[2] - P.z), 0.0f, 0.0f);
+                    boxmask |= 1u << nu;
+                    nu += 2;
                 }
-                c.kind = (prim << 2) | kind;
-                out[n] = c;
+#pragma unroll
+                for (uint32_t j = 0; j < RT_CMAX; ++j) if (j == n) ids[j] = prim;
                 ++n;
             }
         }
-        if (sp == 0) return n;
+        if (sp == 0) return nu | (boxmask << 8);
         --sp;
         const uint2 t = stk.a[sp * STRIDE];
         node = t.x;
