@@ -477,9 +477,11 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene S, FastScene F, Leve
 // (lp.spb * 192 contiguous bytes) are staged through LDS with one coalesced 16-byte load per lane, issued one
 // chunk ahead and parked in registers while the current chunk is classified - the HBM round trip of a chunk
 // overlaps the arithmetic of the previous one.
-#define RT_STAGE 3     // 16-byte units a lane stages per chunk: covers lp.spb * 12 <= 768 units (s*s >= 4)
+// Staging is per WAVE: the <= 9 pairs a wave's 64 lanes belong to (s*s >= 9) are <= 108 units = two 16-byte loads
+// per lane into the wave's own LDS slice, so no workgroup barrier is needed (a wave's DS operations execute in order).
+#define RT_WAVE_UNITS 128
 __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams lp, HitBuf hb, BeamBuf bb, FrameCtl *ctl) {
-    extern __shared__ float4 pair_lds[];
+    __shared__ float4 pair_lds_all[(RT_BLOCK / 64) * RT_WAVE_UNITS];
     if (ctl->overflow) return;
     const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
     const uint32_t s = (uint32_t)lp.sh_rays, s2 = s * s;
@@ -489,15 +491,22 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
     ChunkWalk walk((uint64_t)nchunks * RT_BLOCK);
     uint64_t first;
     const int lane = threadIdx.x & 63;
-    const uint32_t sib = s2 == 1 ? threadIdx.x : __umulhi(threadIdx.x, lp.magic_s2);   // pair within the chunk
+    const uint32_t wave0 = threadIdx.x & ~63u;
+    float4 *pair_lds = pair_lds_all + (threadIdx.x >> 6) * RT_WAVE_UNITS;
+    const uint32_t sib = __umulhi(threadIdx.x, lp.magic_s2);          // pair within the chunk
     const uint32_t kk = threadIdx.x - sib * s2;                        // sample within the pair
     const uint32_t a = s == 1 ? kk : __umulhi(kk, lp.magic_s), b = kk - a * s;   // Light.py:265: jj = a, ii = b
+    // pairs of this wave: first .. last (within the chunk), their units
+    const uint32_t wp0 = __umulhi(wave0, lp.magic_s2);
+    const uint32_t wp1 = min(__umulhi(wave0 + 63u, lp.magic_s2), lp.spb - 1u);
+    const uint32_t wunits = wp1 >= wp0 ? (wp1 - wp0 + 1u) * RT_PAIR_UNITS : 0u;      // <= RT_WAVE_UNITS (host checks s*s >= 9)
+    const uint32_t wbase = wp0 * RT_PAIR_UNITS;
     float pn[RT_PMAX][3];
     for (int k = 0; k < RT_PMAX; ++k)
         for (int c = 0; c < 3; ++c) pn[k][c] = k < S.n_planes ? (float)S.planes[k].n[c] : 0.0f;
-    float4 st0 = make_float4(0, 0, 0, 0), st1 = st0, st2 = st0;
-    const uint32_t i0u = threadIdx.x, i1u = threadIdx.x + RT_BLOCK, i2u = threadIdx.x + 2 * RT_BLOCK;
-#define RT_STAGE_LOAD(src_) do { if (i0u < units) st0 = (src_)[i0u]; if (i1u < units) st1 = (src_)[i1u]; if (i2u < units) st2 = (src_)[i2u]; } while (0)
+    float4 st0 = make_float4(0, 0, 0, 0), st1 = st0;
+    const uint32_t i0u = (uint32_t)lane, i1u = (uint32_t)lane + 64u;
+#define RT_STAGE_LOAD(src_) do { if (i0u < wunits) st0 = (src_)[wbase + i0u]; if (i1u < wunits) st1 = (src_)[wbase + i1u]; } while (0)
     bool have = walk.next(first);
     uint32_t chunk = have ? (uint32_t)(first / RT_BLOCK) : 0u;
     if (have) {
@@ -505,10 +514,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
         RT_STAGE_LOAD(src);
     }
     while (have) {
-        if (i0u < units) pair_lds[i0u] = st0;
-        if (i1u < units) pair_lds[i1u] = st1;
-        if (i2u < units) pair_lds[i2u] = st2;
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // earlier reads of the slice are done (WAR)
+        __builtin_amdgcn_wave_barrier();
+        if (i0u < wunits) pair_lds[i0u] = st0;
+        if (i1u < wunits) pair_lds[i1u] = st1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const uint32_t cur = chunk;
         have = walk.next(first);
         if (have) {                                  // next chunk's records: in flight during the arithmetic below
@@ -520,7 +532,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
         const bool active = sib < lp.spb && seg < nseg;
         bool lit = false, unsure = false;
         if (active) {
-            const float4 *rec = pair_lds + sib * RT_PAIR_UNITS;
+            const float4 *rec = pair_lds + (sib - wp0) * RT_PAIR_UNITS;
             const float4 h0 = rec[0], h1 = rec[1], h2 = rec[2], h3 = rec[3];
             const float g = h0.w;
             const uint32_t meta = __float_as_uint(h1.w);
@@ -545,10 +557,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
                 float w0 = h0.x - bg * h1.x + ag * h2.x + (j10 * h1.x + j20 * h2.x);
                 float w1 = h0.y - bg * h1.y + ag * h2.y + (j11 * h1.y + j21 * h2.y);
                 float w2 = h0.z - bg * h1.z + ag * h2.z + (j12 * h1.z + j22 * h2.z);
-                const float nv = sqrtf(fmaf(w0, w0, fmaf(w1, w1, w2 * w2)));
-                const float inv_nv = 1.0f / nv;
+                const float ww = fmaf(w0, w0, fmaf(w1, w1, w2 * w2));
+                const float inv_nv = __builtin_amdgcn_rsqf(ww);      // 1 ulp: inside the direction-error budget RT_RHO
+                const float nv = ww * inv_nv;
                 w0 *= inv_nv; w1 *= inv_nv; w2 *= inv_nv;
-                const float i0 = 1.0f / w0, i1 = 1.0f / w1, i2 = 1.0f / w2;
                 int n_atp = 0;
                 bool occl = false;
                 if (!(nv > 1e-4f) || !(nv < 1e7f)) unsure = true;
@@ -570,7 +582,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
                     if ((boxmask >> j) & 1u) {
                         const float4 ub = rec[5 + j];
                         k.b[0] = ua.w; k.b[1] = ub.x; k.b[2] = ub.y;
-                        v = sh_box(k, w0, w1, w2, i0, i1, i2, nv);
+                        v = sh_box(k, w0, w1, w2, nv);
                         j += 2;
                     } else {
                         v = sh_sphere(k, w0, w1, w2, nv);
@@ -598,7 +610,6 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
             }
         }
         add_lit_counts(hb.lit, active, lit, active ? (uint64_t)seg : ~0ull, lane);
-        __syncthreads();                             // everyone is done with pair_lds before it is overwritten
     }
 }
 
@@ -1130,7 +1141,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
         ctx->g_shadow = grid_for((const void *)&k_shadow<true>, lds);
         ctx->g_shadow_x = grid_for((const void *)&k_shadow<false>, 0);
         ctx->g_beam_setup = grid_for((const void *)&k_beam_setup, lds * 3 / 2);
-        ctx->g_beam = grid_for((const void *)&k_shadow_beam, 12288);
+        ctx->g_beam = grid_for((const void *)&k_shadow_beam, 0);
         ctx->g_queue = grid_for((const void *)&k_shadow_queue, lds);
         ctx->g_shade = grid_for((const void *)&k_shade, 0);
         ctx->g_setup = grid_for((const void *)&k_shadow_setup, 0);
@@ -1343,7 +1354,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
     const bool prof = (p->flags & RT_FLAG_PROFILE) != 0;
     const bool fast = ctx->F.ok && !(p->flags & RT_FLAG_EXACT_TRAVERSAL);
     const uint32_t s2 = (uint32_t)(sh * sh);
-    const bool beam = fast && ctx->S.n_planes <= RT_PMAX && !(p->flags & RT_FLAG_NO_BEAM) && s2 >= 4 && s2 <= RT_BLOCK &&
+    const bool beam = fast && ctx->S.n_planes <= RT_PMAX && !(p->flags & RT_FLAG_NO_BEAM) && s2 >= 9 && s2 <= RT_BLOCK &&
                       ctx->cap * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1) < 0xFFFFFFFFull;
     if (s2 > 0 && s2 <= RT_BLOCK) {
         lp.spb = RT_BLOCK / s2;
@@ -1364,7 +1375,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
             if (beam) {
                 HIP_TRY(ctx, hipMemsetAsync(ctx->beam.queue_n, 0, sizeof(uint32_t), st));
                 hipLaunchKernelGGL(k_beam_setup, dim3(ctx->g_beam_setup), block, ctx->lds_bytes * 3 / 2, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->beam, ctx->ctl);
-                hipLaunchKernelGGL(k_shadow_beam, dim3(ctx->g_beam), block, (size_t)lp.spb * RT_PAIR_UNITS * sizeof(float4), st, ctx->S, lp, ctx->hb, ctx->beam, ctx->ctl);
+                hipLaunchKernelGGL(k_shadow_beam, dim3(ctx->g_beam), block, 0, st, ctx->S, lp, ctx->hb, ctx->beam, ctx->ctl);
                 hipLaunchKernelGGL(k_shadow_queue, dim3(ctx->g_queue), block, ctx->lds_bytes, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->seg, ctx->beam, ctx->ctl);
             } else {
                 hipLaunchKernelGGL(k_shadow_setup, dim3(ctx->g_setup), block, 0, st, ctx->S, lp, ctx->hb, ctx->seg, ctx->ctl);

@@ -69,7 +69,7 @@ __device__ __forceinline__ int sh_sphere(const CandF &k, float w0, float w1, flo
     const float ed = fmaf(2.0f * fabsf(b), eb, eb * eb) + 4.8e-7f * (b * b + fabsf(k.c));
     if (disc < -ed) return SH_MISS;                                 // the line misses the sphere
     if (!(disc > ed)) return SH_UNSURE;                             // grazing
-    const float sl = sqrtf(disc - ed) * (1.0f - 4.8e-7f), sh = sqrtf(disc + ed) * (1.0f + 4.8e-7f);
+    const float sl = __builtin_amdgcn_sqrtf(disc - ed) * (1.0f - 6e-7f), sh = __builtin_amdgcn_sqrtf(disc + ed) * (1.0f + 6e-7f);
     float lo, hi;
     if (b >= eb) {                    // centre on the light side: tau_out = b + sqrt(disc)
         lo = (b - eb) + sl;
@@ -78,17 +78,19 @@ __device__ __forceinline__ int sh_sphere(const CandF &k, float w0, float w1, flo
         const float qlo = (b - eb) - sh, qhi = (b + eb) - sl;      // both negative
         const float clo = k.c - fabsf(k.c) * 4.8e-7f, chi = k.c + fabsf(k.c) * 4.8e-7f;
         if (!(qhi < 0.0f)) return SH_UNSURE;
-        if (clo >= 0.0f) { lo = chi / qhi; hi = clo / qlo; }       // c >= 0: tau_out <= 0
-        else if (chi <= 0.0f) { lo = chi / qlo; hi = clo / qhi; }  // c <= 0: tau_out >= 0
-        else { lo = chi / qhi; hi = clo / qhi; }
-        lo -= fabsf(lo) * 4.8e-7f;
-        hi += fabsf(hi) * 4.8e-7f;
+        const float rqhi = __builtin_amdgcn_rcpf(qhi), rqlo = __builtin_amdgcn_rcpf(qlo);   // 1 ulp; covered below
+        if (clo >= 0.0f) { lo = chi * rqhi; hi = clo * rqlo; }       // c >= 0: tau_out <= 0
+        else if (chi <= 0.0f) { lo = chi * rqlo; hi = clo * rqhi; }  // c <= 0: tau_out >= 0
+        else { lo = chi * rqhi; hi = clo * rqhi; }
+        lo -= fabsf(lo) * 7e-7f;
+        hi += fabsf(hi) * 7e-7f;
     } else return SH_UNSURE;
     return sh_classify(lo, hi, nv);
 }
 
-__device__ __forceinline__ int sh_box(const CandF &k, float w0, float w1, float w2, float i0, float i1, float i2, float nv) {
+__device__ __forceinline__ int sh_box(const CandF &k, float w0, float w1, float w2, float nv) {
     if (fabsf(w0) < 4e-6f || fabsf(w1) < 4e-6f || fabsf(w2) < 4e-6f) return SH_UNSURE;   // nearly axis parallel
+    const float i0 = __builtin_amdgcn_rcpf(w0), i1 = __builtin_amdgcn_rcpf(w1), i2 = __builtin_amdgcn_rcpf(w2);   // 1 ulp, inside r_k below
     float a0 = k.a[0] * i0, b0 = k.b[0] * i0, a1 = k.a[1] * i1, b1 = k.b[1] * i1, a2 = k.a[2] * i2, b2 = k.b[2] * i2;
     float n0 = fminf(a0, b0), x0 = fmaxf(a0, b0), n1 = fminf(a1, b1), x1 = fmaxf(a1, b1), n2 = fminf(a2, b2), x2 = fmaxf(a2, b2);
     // the direction error is ABSOLUTE (<= RT_RHO per component), so the relative error of a slab distance
@@ -111,10 +113,11 @@ __device__ __forceinline__ int sh_plane(float n0, float n1, float n2, float pd, 
     // tau = -pd / vn
     const float num = -pd;
     float lo, hi;
-    if (num >= 0.0f) { lo = num * (1.0f - 4.8e-7f) / (vn + ev); hi = num * (1.0f + 4.8e-7f) / (vn - ev); }
-    else { lo = num * (1.0f + 4.8e-7f) / (vn - ev); hi = num * (1.0f - 4.8e-7f) / (vn + ev); }
-    lo -= fabsf(lo) * 4.8e-7f;
-    hi += fabsf(hi) * 4.8e-7f;
+    const float rp = __builtin_amdgcn_rcpf(vn + ev), rm = __builtin_amdgcn_rcpf(vn - ev);   // 1 ulp; covered below
+    if (num >= 0.0f) { lo = num * (1.0f - 4.8e-7f) * rp; hi = num * (1.0f + 4.8e-7f) * rm; }
+    else { lo = num * (1.0f + 4.8e-7f) * rm; hi = num * (1.0f - 4.8e-7f) * rp; }
+    lo -= fabsf(lo) * 7e-7f;
+    hi += fabsf(hi) * 7e-7f;
     if (lo > nv + fmaf(nv, 4.0f * RT_RHO, 1e-5f)) return SH_MISS;   // plane beyond the sample (t < 0 from the light)
     return sh_classify(lo, hi, nv);
 }
@@ -163,84 +166,93 @@ __device__ __forceinline__ uint32_t beam_collect(const DScene &S, const FastScen
 #pragma unroll
     for (uint32_t j = 0; j < RT_CMAX; ++j) ids[j] = 0xffffffffu;
     if (!(l0 <= l1)) return 0;
-    (void)n;
-    uint32_t node = 0;
+    // One loop, one memory access per trip: either a node step or a leaf entry.  Lanes of a wave sit at different
+    // places of their own traversals; a flat loop costs the longest single traversal, not the sum of the longest phases.
+    const uint32_t NONE = 0xffffffffu;
+    uint32_t node = 0, e = 0, e_end = 0;
     int sp = 0;
+    float blo0 = 0, blo1 = 0, blo2 = 0, bhi0 = 0, bhi1 = 0, bhi2 = 0;
     for (;;) {
-        KNode nd = F.knodes[node];
-        bool dead = false;
-        while ((nd.b & 3u) != 3u) {
-            const uint32_t ax = nd.b & 3u;
-            const float cut = (__uint_as_float(nd.a) - sel3(ax, Pf0, Pf1, Pf2)) - sel3(ax, Pl0, Pl1, Pl2);
-            float a0 = l0, a1 = l1, b0 = l0, b1 = l1;
-            clip_le(a0, a1, sel3(ax, L0, L1, L2), cut + E);      // left child: some beam point with x <= cut
-            clip_ge(b0, b1, sel3(ax, U0, U1, U2), cut - E);      // right child
-            const bool goL = a0 <= a1, goR = b0 <= b1;
-            if (goL && goR) {
-                stk.a[sp * STRIDE] = make_uint2(nd.b >> 2, __float_as_uint(b0));
-                stk.b[sp * STRIDE] = b1;
-                ++sp;
+        if (e < e_end) {
+            // ---- one leaf entry ----
+            const LeafF lf = F.leaves[e];
+            ++e;
+            const uint32_t kind = lf.pk & 3u, prim = lf.pk >> 2;
+            float plo0, plo1, plo2, phi0, phi1, phi2;
+            bool in_cone = true;
+            if (kind == 1u) {
+                const float c0 = (lf.x - Pf0) + (lf.lx - Pl0), c1 = (lf.y - Pf1) + (lf.ly - Pl1), c2 = (lf.z - Pf2) + (lf.lz - Pl2);
+                plo0 = c0 - lf.r; plo1 = c1 - lf.r; plo2 = c2 - lf.r;
+                phi0 = c0 + lf.r; phi1 = c1 + lf.r; phi2 = c2 + lf.r;
+                // sphere against the cone: distance to the axis <= r (1 + tan) + axial position * tan (conservative)
+                const float ta = fmaf(c0, ax0, fmaf(c1, ax1, c2 * ax2));
+                const float cc = fmaf(c0, c0, fmaf(c1, c1, c2 * c2));
+                const float dp2 = fmaxf(cc - ta * ta, 0.0f);
+                const float lim = fmaf(lf.r, 1.0f + kt, fmaxf(ta, 0.0f) * kt) + E + 2e-6f * sqrtf(cc);
+                in_cone = !(dp2 > lim * lim * 1.0001f) && !(ta < -(lf.r + E)) && !(ta > ax_len * (1.0f + kt) + lf.r + E);
+            } else {
+                plo0 = (lf.x - Pf0) - Pl0; plo1 = (lf.y - Pf1) - Pl1; plo2 = (lf.z - Pf2) - Pl2;
+                phi0 = (lf.lx - Pf0) - Pl0; phi1 = (lf.ly - Pf1) - Pl1; phi2 = (lf.lz - Pf2) - Pl2;
             }
-            if (goL) { node = node + 1; l0 = a0; l1 = a1; }
-            else if (goR) { node = nd.b >> 2; l0 = b0; l1 = b1; }
-            else { dead = true; break; }
-            nd = F.knodes[node];
+            const bool touch = !(plo0 > bhi0) && !(phi0 < blo0) && !(plo1 > bhi1) && !(phi1 < blo1) && !(plo2 > bhi2) && !(phi2 < blo2);
+            if (!touch || !in_cone) continue;
+            bool seen = false;                       // the same primitive is listed in several leaves
+#pragma unroll
+            for (uint32_t j = 0; j < RT_CMAX; ++j) seen = seen || (j < n && ids[j] == prim);
+            if (seen) continue;
+            if (nu + kind > RT_CUNITS) return RT_META_OVERFLOW;       // kind == units needed (sphere 1, box 2)
+            const DPrim *pr = S.prims + prim;
+            if (kind == 1u) {
+                const double dx = pr->a[0] - P.x, dy = pr->a[1] - P.y, dz = pr->a[2] - P.z;
+                out[nu] = make_float4((float)dx, (float)dy, (float)dz, (float)(((dx * dx + dy * dy) + dz * dz) - pr->b[0]));
+                nu += 1;
+            } else {
+                out[nu] = make_float4(__double2float_rd(pr->a[0] - P.x), __double2float_rd(pr->a[1] - P.y),
+                                      __double2float_rd(pr->a[2] - P.z), __double2float_ru(pr->b[0] - P.x));
+                out[nu + 1] = make_float4(__double2float_ru(pr->b[1] - P.y), __double2float_ru(pr->b[2] - P.z), 0.0f, 0.0f);
+                boxmask |= 1u << nu;
+                nu += 2;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < RT_CMAX; ++j) if (j == n) ids[j] = prim;
+            ++n;
+            continue;
         }
-        if (!dead) {
-            // beam bounding box over this leaf's lambda range (slightly widened)
+        if (node == NONE) {
+            if (sp == 0) break;
+            --sp;
+            const uint2 t = stk.a[sp * STRIDE];
+            node = t.x;
+            l0 = __uint_as_float(t.y);
+            l1 = stk.b[sp * STRIDE];
+        }
+        // ---- one node ----
+        const KNode nd = F.knodes[node];
+        if ((nd.b & 3u) == 3u) {
+            // leaf: beam bounding box over this leaf's lambda range (slightly widened)
             const float m0 = fmaxf(l0 - 1e-6f, 0.0f), m1 = fminf(l1 + 1e-6f, 1.0f);
-            const float blo0 = fminf(m0 * L0, m1 * L0) - E, bhi0 = fmaxf(m0 * U0, m1 * U0) + E;
-            const float blo1 = fminf(m0 * L1, m1 * L1) - E, bhi1 = fmaxf(m0 * U1, m1 * U1) + E;
-            const float blo2 = fminf(m0 * L2, m1 * L2) - E, bhi2 = fmaxf(m0 * U2, m1 * U2) + E;
-            const uint32_t first = nd.a, cnt = nd.b >> 2;
-            for (uint32_t e = first; e < first + cnt; ++e) {
-                const LeafF lf = F.leaves[e];
-                const uint32_t kind = lf.pk & 3u, prim = lf.pk >> 2;
-                float plo0, plo1, plo2, phi0, phi1, phi2;
-                bool in_cone = true;
-                if (kind == 1u) {
-                    const float c0 = (lf.x - Pf0) + (lf.lx - Pl0), c1 = (lf.y - Pf1) + (lf.ly - Pl1), c2 = (lf.z - Pf2) + (lf.lz - Pl2);
-                    plo0 = c0 - lf.r; plo1 = c1 - lf.r; plo2 = c2 - lf.r;
-                    phi0 = c0 + lf.r; phi1 = c1 + lf.r; phi2 = c2 + lf.r;
-                    // sphere against the cone: distance to the axis <= r (1 + tan) + axial position * tan (conservative)
-                    const float ta = fmaf(c0, ax0, fmaf(c1, ax1, c2 * ax2));
-                    const float cc = fmaf(c0, c0, fmaf(c1, c1, c2 * c2));
-                    const float dp2 = fmaxf(cc - ta * ta, 0.0f);
-                    const float lim = fmaf(lf.r, 1.0f + kt, fmaxf(ta, 0.0f) * kt) + E + 2e-6f * sqrtf(cc);
-                    in_cone = !(dp2 > lim * lim * 1.0001f) && !(ta < -(lf.r + E)) && !(ta > ax_len * (1.0f + kt) + lf.r + E);
-                } else {
-                    plo0 = (lf.x - Pf0) - Pl0; plo1 = (lf.y - Pf1) - Pl1; plo2 = (lf.z - Pf2) - Pl2;
-                    phi0 = (lf.lx - Pf0) - Pl0; phi1 = (lf.ly - Pf1) - Pl1; phi2 = (lf.lz - Pf2) - Pl2;
-                }
-                const bool touch = !(plo0 > bhi0) && !(phi0 < blo0) && !(plo1 > bhi1) && !(phi1 < blo1) && !(plo2 > bhi2) && !(phi2 < blo2);
-                if (!touch || !in_cone) continue;
-                bool seen = false;                   // the same primitive is listed in several leaves
-#pragma unroll
-                for (uint32_t j = 0; j < RT_CMAX; ++j) seen = seen || (j < n && ids[j] == prim);
-                if (seen) continue;
-                if (nu + kind > RT_CUNITS) return RT_META_OVERFLOW;       // kind == units needed (sphere 1, box 2)
-                const DPrim *pr = S.prims + prim;
-                if (kind == 1u) {
-                    const double dx = pr->a[0] - P.x, dy = pr->a[1] - P.y, dz = pr->a[2] - P.z;
-                    out[nu] = make_float4((float)dx, (float)dy, (float)dz, (float)(((dx * dx + dy * dy) + dz * dz) - pr->b[0]));
-                    nu += 1;
-                } else {
-                    out[nu] = make_float4(__double2float_rd(pr->a[0] - P.x), __double2float_rd(pr->a[1] - P.y),
-                                          __double2float_rd(pr->a[2] - P.z), __double2float_ru(pr->b[0] - P.x));
-                    out[nu + 1] = make_float4(__double2float_ru(pr->b[1] - P.y), __double2float_ru(pr->b[2] - P.z), 0.0f, 0.0f);
-                    boxmask |= 1u << nu;
-                    nu += 2;
-                }
-#pragma unroll
-                for (uint32_t j = 0; j < RT_CMAX; ++j) if (j == n) ids[j] = prim;
-                ++n;
-            }
+            blo0 = fminf(m0 * L0, m1 * L0) - E; bhi0 = fmaxf(m0 * U0, m1 * U0) + E;
+            blo1 = fminf(m0 * L1, m1 * L1) - E; bhi1 = fmaxf(m0 * U1, m1 * U1) + E;
+            blo2 = fminf(m0 * L2, m1 * L2) - E; bhi2 = fmaxf(m0 * U2, m1 * U2) + E;
+            e = nd.a;
+            e_end = nd.a + (nd.b >> 2);
+            node = NONE;
+            continue;
         }
-        if (sp == 0) return nu | (boxmask << 8);
-        --sp;
-        const uint2 t = stk.a[sp * STRIDE];
-        node = t.x;
-        l0 = __uint_as_float(t.y);
-        l1 = stk.b[sp * STRIDE];
+        const uint32_t ax = nd.b & 3u;
+        const float cut = (__uint_as_float(nd.a) - sel3(ax, Pf0, Pf1, Pf2)) - sel3(ax, Pl0, Pl1, Pl2);
+        float a0 = l0, a1 = l1, b0 = l0, b1 = l1;
+        clip_le(a0, a1, sel3(ax, L0, L1, L2), cut + E);      // left child: some beam point with x <= cut
+        clip_ge(b0, b1, sel3(ax, U0, U1, U2), cut - E);      // right child
+        const bool goL = a0 <= a1, goR = b0 <= b1;
+        if (goL && goR) {
+            stk.a[sp * STRIDE] = make_uint2(nd.b >> 2, __float_as_uint(b0));
+            stk.b[sp * STRIDE] = b1;
+            ++sp;
+        }
+        if (goL) { node = node + 1; l0 = a0; l1 = a1; }
+        else if (goR) { node = nd.b >> 2; l0 = b0; l1 = b1; }
+        else node = NONE;
     }
+    return nu | (boxmask << 8);
 }
