@@ -267,16 +267,16 @@ inline void pcg3d(uint32_t &x, uint32_t &y, uint32_t &z) {
     x ^= x >> 16; y ^= y >> 16; z ^= z >> 16;
     x += y * z; y += z * x; z += x * y;
 }
+/* One hash per shadow ray; the high halves of (x, y, z) are the first draw of Light.py:277, the low halves the
+ * second (16 bits per deviate: steps of g / 32768). */
 inline void jitter6(uint32_t seed, uint32_t pixel, uint32_t path, uint32_t light, uint32_t sample, double g,
                     double out[6]) {
-    for (uint32_t st = 0; st < 2; ++st) {
-        uint32_t x = pixel, y = path * 0x9E3779B1u + light, z = seed * 0x85EBCA6Bu + sample * 2u + st;
-        pcg3d(x, y, z);
-        const uint32_t h[3] = {x, y, z};
-        for (int k = 0; k < 3; ++k) {
-            double u = (double)(h[k] >> 8) * (1.0 / 16777216.0);
-            out[3 * st + k] = -g + (2 * g) * u;
-        }
+    uint32_t x = pixel, y = path * 0x9E3779B1u + light, z = seed * 0x85EBCA6Bu + sample;
+    pcg3d(x, y, z);
+    const uint32_t h[6] = {x >> 16, y >> 16, z >> 16, x & 0xffffu, y & 0xffffu, z & 0xffffu};
+    for (int k = 0; k < 6; ++k) {
+        double u = (double)h[k] * (1.0 / 65536.0);
+        out[k] = -g + (2 * g) * u;
     }
 }
 

@@ -78,6 +78,7 @@ struct LevelParams {
     int32_t flags;
     // beam path: a chunk of RT_BLOCK lanes holds spb whole (hit, light) pairs of s2 rays each
     uint32_t spb, magic_s2, magic_s;     // magic_x = ceil(2^32 / x): n / x == __umulhi(n, magic_x) for n < 2^16
+    int32_t beam;                        // this frame's soft shadows go through the beam path
 };
 
 // XCD-aware chunk walk: workgroups b and b+8 share an XCD (and its L2), so XCD x = b % 8 walks one
@@ -388,7 +389,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_beam_setup(DScene S, FastScene F, 
         uint32_t nc = RT_META_OVERFLOW;
         if (!delicate && (lp.flags & 0x100)) nc = 0;   // timing experiment only
         else if (!delicate) nc = beam_collect<RT_BLOCK>(S, F, bs, P, cB0, cB1, cB2, h0, h1, h2, rec + 4);
-        rec[1] = make_float4(u0, u1, u2, __uint_as_float(nc | ((uint32_t)m << 16)));
+        uint32_t pcls = 0;                             // whole-pair verdicts of the planes
+#pragma unroll
+        for (int k = 0; k < RT_PMAX; ++k)
+            if (k < S.n_planes)
+                pcls |= sh_plane_pair((float)S.planes[k].n[0], (float)S.planes[k].n[1], (float)S.planes[k].n[2], pd[k], cB0, cB1, cB2,
+                                      h0, h1, h2) << (2 * k);
+        rec[1] = make_float4(u0, u1, u2, __uint_as_float(nc | ((uint32_t)m << 16) | (pcls << 24)));
     }
 }
 
@@ -474,11 +481,12 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene S, FastScene F, Leve
 
 // one lane per soft-shadow ray, float32 filtered predicates on the pair's candidate list (rt_shadow.hpp);
 // undecided rays go to the queue.  A chunk of RT_BLOCK lanes holds lp.spb whole pairs; their records
-// (lp.spb * 192 contiguous bytes) are staged through LDS with one coalesced 16-byte load per lane, issued one
-// chunk ahead and parked in registers while the current chunk is classified - the HBM round trip of a chunk
-// overlaps the arithmetic of the previous one.
+// (lp.spb * 192 contiguous bytes) are staged through LDS with 16-byte loads issued one chunk ahead and parked
+// in registers while the current chunk is classified - the HBM round trip of a chunk overlaps the arithmetic
+// of the previous one.
 // Staging is per WAVE: the <= 9 pairs a wave's 64 lanes belong to (s*s >= 9) are <= 108 units = two 16-byte loads
 // per lane into the wave's own LDS slice, so no workgroup barrier is needed (a wave's DS operations execute in order).
+// The lane -> (pair, sample) map is the same in every chunk, so is the wave's segment structure for the lit counts.
 #define RT_WAVE_UNITS 128
 __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams lp, HitBuf hb, BeamBuf bb, FrameCtl *ctl) {
     __shared__ float4 pair_lds_all[(RT_BLOCK / 64) * RT_WAVE_UNITS];
@@ -496,14 +504,25 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
     const uint32_t sib = __umulhi(threadIdx.x, lp.magic_s2);          // pair within the chunk
     const uint32_t kk = threadIdx.x - sib * s2;                        // sample within the pair
     const uint32_t a = s == 1 ? kk : __umulhi(kk, lp.magic_s), b = kk - a * s;   // Light.py:265: jj = a, ii = b
+    const float fa = (float)a, fb = (float)b;
     // pairs of this wave: first .. last (within the chunk), their units
     const uint32_t wp0 = __umulhi(wave0, lp.magic_s2);
     const uint32_t wp1 = min(__umulhi(wave0 + 63u, lp.magic_s2), lp.spb - 1u);
     const uint32_t wunits = wp1 >= wp0 ? (wp1 - wp0 + 1u) * RT_PAIR_UNITS : 0u;      // <= RT_WAVE_UNITS (host checks s*s >= 9)
     const uint32_t wbase = wp0 * RT_PAIR_UNITS;
+    const float4 *rec = pair_lds + (sib < lp.spb ? (sib - wp0) * RT_PAIR_UNITS : 0u);
+    // Lit verdicts leave as one 64-bit ballot per wave and chunk (k_shade counts the bits of a pair).  No global
+    // atomic or store sits in the steady-state loop - the wait for the staged loads at the top of an iteration
+    // would otherwise also wait for them (one vmcnt) - : lane l of the wave parks the ballot of iteration
+    // 64 w + l, and the wave stores 64 of them at once.
+    const uint32_t wave = threadIdx.x >> 6;
+    unsigned long long keep = 0ull;
+    uint32_t it = 0u, win_chunk = 0u;
+    const uint32_t cstep = walk.step;
     float pn[RT_PMAX][3];
     for (int k = 0; k < RT_PMAX; ++k)
         for (int c = 0; c < 3; ++c) pn[k][c] = k < S.n_planes ? (float)S.planes[k].n[c] : 0.0f;
+    const uint32_t zkey = lp.seed * 0x85EBCA6Bu + kk;
     float4 st0 = make_float4(0, 0, 0, 0), st1 = st0;
     const uint32_t i0u = (uint32_t)lane, i1u = (uint32_t)lane + 64u;
 #define RT_STAGE_LOAD(src_) do { if (i0u < wunits) st0 = (src_)[wbase + i0u]; if (i1u < wunits) st1 = (src_)[wbase + i1u]; } while (0)
@@ -532,85 +551,89 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
         const bool active = sib < lp.spb && seg < nseg;
         bool lit = false, unsure = false;
         if (active) {
-            const float4 *rec = pair_lds + (sib - wp0) * RT_PAIR_UNITS;
             const float4 h0 = rec[0], h1 = rec[1], h2 = rec[2], h3 = rec[3];
             const float g = h0.w;
             const uint32_t meta = __float_as_uint(h1.w);
             const uint32_t nu = meta & 0xffu, boxmask = (meta >> 8) & 0xffu;
             if (nu == RT_META_OVERFLOW) unsure = true;
             else {
-                float j10 = 0, j11 = 0, j12 = 0, j20 = 0, j21 = 0, j22 = 0;
-                if (lp.jitter) {
-                    const uint32_t m = meta >> 16;
-                    const float k24 = 1.0f / 16777216.0f, g2 = 2.0f * g;
-                    uint32_t x = __float_as_uint(h2.w), y = __float_as_uint(h3.w) * 0x9E3779B1u + m, z = lp.seed * 0x85EBCA6Bu + kk * 2u;
-                    uint32_t x2 = x, y2 = y, z2 = z + 1u;
+                float j10 = 0, j11 = 0, j12 = 0, j20 = 0, j21 = 0, j22 = 0;   // Light.py:277-278: one deviation per component
+                if (lp.jitter) {                     // jitter6() of the oracle, in float32
+                    const uint32_t m = (meta >> 16) & 0xffu;
+                    const float k16 = 1.0f / 65536.0f, g2 = 2.0f * g;
+                    uint32_t x = __float_as_uint(h2.w), y = __float_as_uint(h3.w) * 0x9E3779B1u + m, z = zkey;
                     pcg3d(x, y, z);
-                    pcg3d(x2, y2, z2);
-                    j10 = fmaf(g2, (float)(x >> 8) * k24, -g); j11 = fmaf(g2, (float)(y >> 8) * k24, -g);
-                    j12 = fmaf(g2, (float)(z >> 8) * k24, -g);
-                    j20 = fmaf(g2, (float)(x2 >> 8) * k24, -g); j21 = fmaf(g2, (float)(y2 >> 8) * k24, -g);
-                    j22 = fmaf(g2, (float)(z2 >> 8) * k24, -g);
+                    j10 = fmaf(g2, (float)(x >> 16) * k16, -g); j11 = fmaf(g2, (float)(y >> 16) * k16, -g);
+                    j12 = fmaf(g2, (float)(z >> 16) * k16, -g);
+                    j20 = fmaf(g2, (float)(x & 0xffffu) * k16, -g); j21 = fmaf(g2, (float)(y & 0xffffu) * k16, -g);
+                    j22 = fmaf(g2, (float)(z & 0xffffu) * k16, -g);
                 }
                 // w = sample - P (Light.py:273-279), float32
-                const float bg = (float)b * g, ag = (float)a * g;
+                const float bg = fb * g, ag = fa * g;
                 float w0 = h0.x - bg * h1.x + ag * h2.x + (j10 * h1.x + j20 * h2.x);
                 float w1 = h0.y - bg * h1.y + ag * h2.y + (j11 * h1.y + j21 * h2.y);
                 float w2 = h0.z - bg * h1.z + ag * h2.z + (j12 * h1.z + j22 * h2.z);
                 const float ww = fmaf(w0, w0, fmaf(w1, w1, w2 * w2));
                 const float inv_nv = __builtin_amdgcn_rsqf(ww);      // 1 ulp: inside the direction-error budget RT_RHO
                 const float nv = ww * inv_nv;
+                const float nvlim = nv - fmaf(nv, 4.0f * RT_RHO, 1e-5f);
                 w0 *= inv_nv; w1 *= inv_nv; w2 *= inv_nv;
+                int verdict = (!(nv > 1e-4f) || !(nv < 1e7f)) ? SH_UNSURE : 0;
                 int n_atp = 0;
-                bool occl = false;
-                if (!(nv > 1e-4f) || !(nv < 1e7f)) unsure = true;
                 const float pdk[RT_PMAX] = {h3.x, h3.y, h3.z};
+                const uint32_t pcls = meta >> 24;
 #pragma unroll
                 for (int k = 0; k < RT_PMAX; ++k) {
                     if (k < S.n_planes) {
-                        int v = sh_plane(pn[k][0], pn[k][1], pn[k][2], pdk[k], w0, w1, w2, nv);
-                        occl = occl || v == SH_OCCLUDE;
-                        unsure = unsure || v == SH_UNSURE;
-                        n_atp += v == SH_ATP;
+                        const uint32_t cls = (pcls >> (2 * k)) & 3u;
+                        if (cls == RT_PLANE_EVAL) {
+                            const int v = sh_plane(pn[k][0], pn[k][1], pn[k][2], pdk[k], w0, w1, w2, nv, nvlim);
+                            verdict |= v;
+                            n_atp += v & SH_ATP;
+                        } else n_atp += cls == RT_PLANE_ATP;
                     }
                 }
-                for (uint32_t j = 0; j < nu && !occl;) {
+                RayInv qi;
+                if (boxmask) qi = sh_ray_inv(w0, w1, w2);
+                for (uint32_t j = 0; j < nu && !(verdict & SH_OCCLUDE);) {
                     const float4 ua = rec[4 + j];
-                    CandF k;
-                    k.a[0] = ua.x; k.a[1] = ua.y; k.a[2] = ua.z; k.c = ua.w;
                     int v;
                     if ((boxmask >> j) & 1u) {
                         const float4 ub = rec[5 + j];
-                        k.b[0] = ua.w; k.b[1] = ub.x; k.b[2] = ub.y;
-                        v = sh_box(k, w0, w1, w2, nv);
+                        v = sh_box(ua.x, ua.y, ua.z, ua.w, ub.x, ub.y, qi, nvlim);
                         j += 2;
                     } else {
-                        v = sh_sphere(k, w0, w1, w2, nv);
+                        v = sh_sphere(ua.x, ua.y, ua.z, ua.w, w0, w1, w2, nvlim);
                         j += 1;
                     }
-                    occl = occl || v == SH_OCCLUDE;
-                    unsure = unsure || v == SH_UNSURE;
-                    n_atp += v == SH_ATP;
+                    verdict |= v;
+                    n_atp += v & SH_ATP;
                 }
-                if (occl) unsure = false;           // one certain occluder settles the ray
-                else if (!unsure) lit = n_atp > 0;
+                if (verdict & SH_OCCLUDE) unsure = false;        // one certain occluder settles the ray
+                else if (verdict & SH_UNSURE) unsure = true;
+                else lit = n_atp > 0;
             }
         }
         // undecided rays -> queue (one atomic per wave)
         unsigned long long um = __ballot(unsure);
         if (um) {
-            int leader = __ffsll((long long)um) - 1;
+            int qleader = __ffsll((long long)um) - 1;
             uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&bb.queue_n[0], (uint32_t)__popcll(um));
-            base = __shfl(base, leader);
+            if (lane == qleader) base = atomicAdd(&bb.queue_n[0], (uint32_t)__popcll(um));
+            base = __shfl(base, qleader);
             if (unsure) {
                 uint32_t at = base + (uint32_t)__popcll(um & ((1ull << lane) - 1ull));
                 if (at < bb.queue_n[1]) bb.queue[at] = (unsigned long long)seg * s2 + kk;
                 else ctl->overflow = 1;             // frame is void; the host re-renders with a larger queue
             }
         }
-        add_lit_counts(hb.lit, active, lit, active ? (uint64_t)seg : ~0ull, lane);
+        const unsigned long long lm = __ballot(lit);
+        if ((it & 63u) == 0u) win_chunk = cur;
+        if ((uint32_t)lane == (it & 63u)) keep = lm;
+        ++it;
+        if ((it & 63u) == 0u) bb.litbits[((uint64_t)win_chunk + (uint64_t)lane * cstep) * (RT_BLOCK / 64) + wave] = keep;
     }
+    if ((uint32_t)lane < (it & 63u)) bb.litbits[((uint64_t)win_chunk + (uint64_t)lane * cstep) * (RT_BLOCK / 64) + wave] = keep;
 }
 
 // the rays the filter could not decide, in float64
@@ -633,7 +656,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_queue(DScene S, FastScene F
 
 // Phong shading + secondary-ray generation for every hit of the level
 __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, LevelParams lp, RayQ q, RayQ qn, HitBuf hb, FrameCtl *ctl,
-                                                    double *fb) {
+                                                    double *fb, const unsigned long long *litbits) {
     if (ctl->overflow) return;
     const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
     const uint32_t nsl = (uint32_t)S.n_shadow_lights;
@@ -678,6 +701,17 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, LevelParams lp, Ra
                     uint64_t seg = (uint64_t)h * nsl + ml;
                     uint32_t cnt = hb.lit[seg];
                     hb.lit[seg] = 0;                                     // ready for the next level
+                    if (lp.beam) {                                       // + the filter's verdicts: lanes [lo, lo + s*s) of the pair's chunk
+                        const uint32_t chunk = (uint32_t)seg / lp.spb, sib = (uint32_t)seg - chunk * lp.spb;
+                        const uint32_t lo = sib * (uint32_t)(lp.sh_rays * lp.sh_rays), hi = lo + (uint32_t)(lp.sh_rays * lp.sh_rays);
+                        const unsigned long long *bits = litbits + (uint64_t)chunk * (RT_BLOCK / 64);
+                        for (uint32_t w = lo >> 6; w <= ((hi - 1u) >> 6); ++w) {
+                            const uint32_t b0 = w << 6;
+                            const uint32_t l = lo > b0 ? lo - b0 : 0u, u = hi < b0 + 64u ? hi - b0 : 64u;   // bit range [l, u) of word w
+                            const unsigned long long m = (u == 64u ? ~0ull : ((1ull << u) - 1ull)) & ~((1ull << l) - 1ull);
+                            cnt += (uint32_t)__popcll(bits[w] & m);
+                        }
+                    }
                     ml++;
                     double frac = (double)cnt / s2;                  // Light.py:223
                     I = (1.0 - Lt.shadow) + Lt.shadow * frac;            // Light.py:226
@@ -1263,6 +1297,7 @@ static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
     ctx->beam_queue_cap = (uint32_t)(cap < 0x7fffffffull ? cap : 0x7fffffffull);
     TRY_A(dalloc(ctx, &bb.rec, (nlit + RT_BLOCK) * RT_PAIR_UNITS));   // + one chunk of slack: staging reads whole chunks
     TRY_A(dalloc(ctx, &bb.queue, (uint64_t)ctx->beam_queue_cap)); TRY_A(dalloc(ctx, &bb.queue_n, 2));
+    TRY_A(dalloc(ctx, &bb.litbits, (nlit + 1) * (RT_BLOCK / 64)));      // worst case one pair per chunk (s*s > RT_BLOCK / 2)
     {
         uint32_t init[2] = {0u, ctx->beam_queue_cap};
         HIP_TRY(ctx, hipMemcpy(bb.queue_n, init, sizeof(init), hipMemcpyHostToDevice));
@@ -1355,9 +1390,12 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
     const bool fast = ctx->F.ok && !(p->flags & RT_FLAG_EXACT_TRAVERSAL);
     const uint32_t s2 = (uint32_t)(sh * sh);
     const bool beam = fast && ctx->S.n_planes <= RT_PMAX && !(p->flags & RT_FLAG_NO_BEAM) && s2 >= 9 && s2 <= RT_BLOCK &&
+                      ctx->S.n_lights <= 256 &&   // pair record: 8-bit light index
+
                       ctx->cap * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1) < 0xFFFFFFFFull;
     if (s2 > 0 && s2 <= RT_BLOCK) {
         lp.spb = RT_BLOCK / s2;
+        lp.beam = beam ? 1 : 0;
         lp.magic_s2 = (uint32_t)((0x100000000ull + s2 - 1) / s2);
         lp.magic_s = (uint32_t)((0x100000000ull + (uint32_t)sh - 1) / (uint32_t)sh);
     }
@@ -1385,7 +1423,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         }
         PROF_MARK(e + 3);
         PROF_MARK(e + 4);
-        hipLaunchKernelGGL(k_shade, dim3(ctx->g_shade), block, 0, st, ctx->S, lp, qc, qn, ctx->hb, ctx->ctl, ctx->fb);
+        hipLaunchKernelGGL(k_shade, dim3(ctx->g_shade), block, 0, st, ctx->S, lp, qc, qn, ctx->hb, ctx->ctl, ctx->fb, ctx->beam.litbits);
         PROF_MARK(e + 5);
     }
     HIP_TRY(ctx, hipGetLastError());

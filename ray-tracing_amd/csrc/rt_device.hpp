@@ -204,13 +204,15 @@ __device__ __forceinline__ void pcg3d(uint32_t &x, uint32_t &y, uint32_t &z) {
     x ^= x >> 16; y ^= y >> 16; z ^= z >> 16;
     x += y * z; y += z * x; z += x * y;
 }
+// stream 0 / 1 = the two draws of Light.py:277-278; ONE hash per shadow ray, 16 bits per deviate
 __device__ __forceinline__ d3 jitter3(uint32_t seed, uint32_t pixel, uint32_t path, uint32_t light, uint32_t sample,
                                       uint32_t stream, double g) {
-    uint32_t x = pixel, y = path * 0x9E3779B1u + light, z = seed * 0x85EBCA6Bu + sample * 2u + stream;
+    uint32_t x = pixel, y = path * 0x9E3779B1u + light, z = seed * 0x85EBCA6Bu + sample;
     pcg3d(x, y, z);
-    const double k = 1.0 / 16777216.0;
-    return mk3(-g + (2 * g) * ((double)(x >> 8) * k), -g + (2 * g) * ((double)(y >> 8) * k),
-               -g + (2 * g) * ((double)(z >> 8) * k));
+    if (stream == 0u) { x >>= 16; y >>= 16; z >>= 16; }
+    else { x &= 0xffffu; y &= 0xffffu; z &= 0xffffu; }
+    const double k = 1.0 / 65536.0;
+    return mk3(-g + (2 * g) * ((double)x * k), -g + (2 * g) * ((double)y * k), -g + (2 * g) * ((double)z * k));
 }
 
 // util.get_orthonormal_vector (util.py:113-132) + create_orthonormal_basis (util.py:65-75)

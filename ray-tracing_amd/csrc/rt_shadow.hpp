@@ -44,94 +44,129 @@ struct BeamBuf {
     float4 *rec;             // [pair][RT_PAIR_UNITS]
     unsigned long long *queue;   // shadow-ray numbers g the filter could not decide
     uint32_t *queue_n;       // [0] = entries appended, [1] = capacity
+    unsigned long long *litbits; // [chunk][wave]: which lanes' rays the filter found lit (every word written per level)
 };
 #define RT_META_OVERFLOW 0xFFu
 
 #define RT_T1 1e-6f          // the reference's EPSILON (Light.py:221)
 #define RT_RHO 1.9073486e-06f   // 2^-19: bound on the ABSOLUTE error of the float32 unit direction w (measured need ~5e-7)
 
-enum { SH_MISS = 0, SH_ATP = 1, SH_OCCLUDE = 2, SH_UNSURE = 3 };
+enum { SH_MISS = 0, SH_ATP = 1, SH_OCCLUDE = 2, SH_UNSURE = 4 };   // verdict bits: a ray ORs them over its candidates
 
-// verdict for one primitive from conservative bounds [lo, hi] of tau_out; nv = |sample - P|
-__device__ __forceinline__ int sh_classify(float lo, float hi, float nv) {
-    if (!(lo <= hi)) return SH_UNSURE;                             // NaN somewhere
-    if (hi < -1.1f * RT_T1) return SH_MISS;                         // entirely behind P
-    if (lo > 1.1f * RT_T1) return (hi < nv - fmaf(nv, 4.0f * RT_RHO, 1e-5f)) ? SH_OCCLUDE : SH_UNSURE;
-    if (lo > -0.9f * RT_T1 && hi < 0.9f * RT_T1) return SH_ATP;
-    return SH_UNSURE;
+// Everything below is written without branches: the lanes of a wave look at different candidates of different
+// pairs, so every path is paid for anyway, and selects cost less than the exec-mask bookkeeping of nested ifs.
+
+// verdict for one primitive from conservative bounds [lo, hi] of tau_out.  nvlim = nv - (4 rho nv + 1e-5), nv = |sample - P|:
+// an entry point below nvlim certainly lies between P and the sample.
+__device__ __forceinline__ int sh_classify(float lo, float hi, float nvlim) {
+    const bool ok = lo <= hi;                                       // false: NaN somewhere
+    const bool miss = hi < -1.1f * RT_T1;                           // entirely behind P
+    const bool occ = lo > 1.1f * RT_T1 && hi < nvlim;
+    const bool atp = lo > -0.9f * RT_T1 && hi < 0.9f * RT_T1;
+    return !ok ? SH_UNSURE : miss ? SH_MISS : occ ? SH_OCCLUDE : atp ? SH_ATP : SH_UNSURE;
 }
 
-__device__ __forceinline__ int sh_sphere(const CandF &k, float w0, float w1, float w2, float nv) {
-    const float b = fmaf(w0, k.a[0], fmaf(w1, k.a[1], w2 * k.a[2]));
-    const float eb = RT_2M20 * (fabsf(w0 * k.a[0]) + fabsf(w1 * k.a[1]) + fabsf(w2 * k.a[2])) +
-                     RT_RHO * (fabsf(k.a[0]) + fabsf(k.a[1]) + fabsf(k.a[2]));
-    const float disc = fmaf(b, b, -k.c);
-    const float ed = fmaf(2.0f * fabsf(b), eb, eb * eb) + 4.8e-7f * (b * b + fabsf(k.c));
-    if (disc < -ed) return SH_MISS;                                 // the line misses the sphere
-    if (!(disc > ed)) return SH_UNSURE;                             // grazing
-    const float sl = __builtin_amdgcn_sqrtf(disc - ed) * (1.0f - 6e-7f), sh = __builtin_amdgcn_sqrtf(disc + ed) * (1.0f + 6e-7f);
-    float lo, hi;
-    if (b >= eb) {                    // centre on the light side: tau_out = b + sqrt(disc)
-        lo = (b - eb) + sl;
-        hi = (b + eb) + sh;
-    } else if (b <= -eb) {            // centre away from the light: tau_out = c / (b - sqrt(disc)), stable form
-        const float qlo = (b - eb) - sh, qhi = (b + eb) - sl;      // both negative
-        const float clo = k.c - fabsf(k.c) * 4.8e-7f, chi = k.c + fabsf(k.c) * 4.8e-7f;
-        if (!(qhi < 0.0f)) return SH_UNSURE;
-        const float rqhi = __builtin_amdgcn_rcpf(qhi), rqlo = __builtin_amdgcn_rcpf(qlo);   // 1 ulp; covered below
-        if (clo >= 0.0f) { lo = chi * rqhi; hi = clo * rqlo; }       // c >= 0: tau_out <= 0
-        else if (chi <= 0.0f) { lo = chi * rqlo; hi = clo * rqhi; }  // c <= 0: tau_out >= 0
-        else { lo = chi * rqhi; hi = clo * rqhi; }
-        lo -= fabsf(lo) * 7e-7f;
-        hi += fabsf(hi) * 7e-7f;
-    } else return SH_UNSURE;
-    return sh_classify(lo, hi, nv);
-}
-
-__device__ __forceinline__ int sh_box(const CandF &k, float w0, float w1, float w2, float nv) {
-    if (fabsf(w0) < 4e-6f || fabsf(w1) < 4e-6f || fabsf(w2) < 4e-6f) return SH_UNSURE;   // nearly axis parallel
-    const float i0 = __builtin_amdgcn_rcpf(w0), i1 = __builtin_amdgcn_rcpf(w1), i2 = __builtin_amdgcn_rcpf(w2);   // 1 ulp, inside r_k below
-    float a0 = k.a[0] * i0, b0 = k.b[0] * i0, a1 = k.a[1] * i1, b1 = k.b[1] * i1, a2 = k.a[2] * i2, b2 = k.b[2] * i2;
-    float n0 = fminf(a0, b0), x0 = fmaxf(a0, b0), n1 = fminf(a1, b1), x1 = fmaxf(a1, b1), n2 = fminf(a2, b2), x2 = fmaxf(a2, b2);
-    // the direction error is ABSOLUTE (<= RT_RHO per component), so the relative error of a slab distance
-    // along axis k is RT_RHO / |w_k| (+ arithmetic)
-    const float r0 = fmaf(RT_RHO, fabsf(i0), RT_2M20), r1 = fmaf(RT_RHO, fabsf(i1), RT_2M20), r2 = fmaf(RT_RHO, fabsf(i2), RT_2M20);
-    float en_lo = fmaxf(fmaxf(n0 - fabsf(n0) * r0, n1 - fabsf(n1) * r1), n2 - fabsf(n2) * r2);
-    float en_hi = fmaxf(fmaxf(n0 + fabsf(n0) * r0, n1 + fabsf(n1) * r1), n2 + fabsf(n2) * r2);
-    float ex_lo = fminf(fminf(x0 - fabsf(x0) * r0, x1 - fabsf(x1) * r1), x2 - fabsf(x2) * r2);
-    float ex_hi = fminf(fminf(x0 + fabsf(x0) * r0, x1 + fabsf(x1) * r1), x2 + fabsf(x2) * r2);
-    if (en_lo > ex_hi) return SH_MISS;                              // the line misses the box
-    if (!(en_hi < ex_lo)) return SH_UNSURE;                         // touching an edge / corner
-    return sh_classify(ex_lo, ex_hi, nv);                           // the light ray enters at tau = exit
-}
-
-__device__ __forceinline__ int sh_plane(float n0, float n1, float n2, float pd, float w0, float w1, float w2, float nv) {
-    const float vn = fmaf(w0, n0, fmaf(w1, n1, w2 * n2));
-    const float ev = 2.5f * RT_RHO;                                 // |n|_1 <= 1.74, plus the rounding of n and the dot product
-    if (vn < -ev) return SH_MISS;                                   // the light ray sees the back: one-sided (InfinitePlane.py:83)
-    if (!(vn > ev)) return SH_UNSURE;
-    // tau = -pd / vn
-    const float num = -pd;
-    float lo, hi;
-    const float rp = __builtin_amdgcn_rcpf(vn + ev), rm = __builtin_amdgcn_rcpf(vn - ev);   // 1 ulp; covered below
-    if (num >= 0.0f) { lo = num * (1.0f - 4.8e-7f) * rp; hi = num * (1.0f + 4.8e-7f) * rm; }
-    else { lo = num * (1.0f + 4.8e-7f) * rm; hi = num * (1.0f - 4.8e-7f) * rp; }
+// sphere {a = centre - P, c = |centre - P|^2 - r^2}.  With b = w.a and D = b^2 - c the light ray enters at
+// tau_out = b + sqrt(D); for b < 0 the stable form is  -c / (|b| + sqrt(D)).
+__device__ __forceinline__ int sh_sphere(float a0, float a1, float a2, float c, float w0, float w1, float w2, float nvlim) {
+    const float b = fmaf(w0, a0, fmaf(w1, a1, w2 * a2));
+    const float eb = RT_2M20 * (fabsf(w0 * a0) + fabsf(w1 * a1) + fabsf(w2 * a2)) + RT_RHO * (fabsf(a0) + fabsf(a1) + fabsf(a2));
+    const float disc = fmaf(b, b, -c);
+    const float ed = fmaf(2.0f * fabsf(b), eb, eb * eb) + 4.8e-7f * (b * b + fabsf(c));
+    const bool miss = disc < -ed;                                   // the line misses the sphere
+    const bool clear = disc > ed;                                   // else grazing
+    const float sl = __builtin_amdgcn_sqrtf(fmaxf(disc - ed, 0.0f)) * (1.0f - 6e-7f);
+    const float sh = __builtin_amdgcn_sqrtf(disc + ed) * (1.0f + 6e-7f);
+    const float ab = fabsf(b);
+    const float qa = (ab - eb) + sl, qb = (ab + eb) + sh;           // bounds of |b| + sqrt(D)
+    const float cw = fabsf(c) * 4.8e-7f;
+    const float nlo = -c - cw, nhi = -c + cw;                       // bounds of -c
+    const float rqa = __builtin_amdgcn_rcpf(qa), rqb = __builtin_amdgcn_rcpf(qb);   // 1 ulp; covered by the 7e-7 below
+    float lo = nlo * (nlo >= 0.0f ? rqb : rqa), hi = nhi * (nhi >= 0.0f ? rqa : rqb);
     lo -= fabsf(lo) * 7e-7f;
     hi += fabsf(hi) * 7e-7f;
-    if (lo > nv + fmaf(nv, 4.0f * RT_RHO, 1e-5f)) return SH_MISS;   // plane beyond the sample (t < 0 from the light)
-    return sh_classify(lo, hi, nv);
+    const bool front = b > 0.0f;                                    // centre on the light side of P
+    lo = front ? qa : lo;
+    hi = front ? qb : hi;
+    const bool sure = clear && ab >= eb && (front || qa > 0.0f);
+    const int v = sh_classify(lo, hi, nvlim);
+    return miss ? SH_MISS : sure ? v : SH_UNSURE;
+}
+
+struct RayInv {              // per ray, shared by all its box candidates
+    float i0, i1, i2;        // 1 / w_k (1 ulp)
+    float r0, r1, r2;        // relative error of a slab distance along axis k: the direction error is ABSOLUTE
+                             // (<= RT_RHO per component), so it is RT_RHO / |w_k| (+ arithmetic)
+    bool ok;                 // false: nearly axis parallel
+};
+__device__ __forceinline__ RayInv sh_ray_inv(float w0, float w1, float w2) {
+    RayInv v;
+    v.ok = !(fminf(fminf(fabsf(w0), fabsf(w1)), fabsf(w2)) < 4e-6f);
+    v.i0 = __builtin_amdgcn_rcpf(w0); v.i1 = __builtin_amdgcn_rcpf(w1); v.i2 = __builtin_amdgcn_rcpf(w2);
+    v.r0 = fmaf(RT_RHO, fabsf(v.i0), RT_2M20); v.r1 = fmaf(RT_RHO, fabsf(v.i1), RT_2M20); v.r2 = fmaf(RT_RHO, fabsf(v.i2), RT_2M20);
+    return v;
+}
+// box {lo - P rounded down, hi - P rounded up}
+__device__ __forceinline__ int sh_box(float lo0, float lo1, float lo2, float hi0, float hi1, float hi2, const RayInv &q, float nvlim) {
+    const float a0 = lo0 * q.i0, b0 = hi0 * q.i0, a1 = lo1 * q.i1, b1 = hi1 * q.i1, a2 = lo2 * q.i2, b2 = hi2 * q.i2;
+    const float n0 = fminf(a0, b0), x0 = fmaxf(a0, b0), n1 = fminf(a1, b1), x1 = fmaxf(a1, b1), n2 = fminf(a2, b2), x2 = fmaxf(a2, b2);
+    const float dn0 = fabsf(n0) * q.r0, dn1 = fabsf(n1) * q.r1, dn2 = fabsf(n2) * q.r2;
+    const float dx0 = fabsf(x0) * q.r0, dx1 = fabsf(x1) * q.r1, dx2 = fabsf(x2) * q.r2;
+    const float en_lo = fmaxf(fmaxf(n0 - dn0, n1 - dn1), n2 - dn2), en_hi = fmaxf(fmaxf(n0 + dn0, n1 + dn1), n2 + dn2);
+    const float ex_lo = fminf(fminf(x0 - dx0, x1 - dx1), x2 - dx2), ex_hi = fminf(fminf(x0 + dx0, x1 + dx1), x2 + dx2);
+    const bool miss = en_lo > ex_hi;                                // the line misses the box
+    const bool clean = en_hi < ex_lo;                               // else touching an edge / corner
+    const int v = sh_classify(ex_lo, ex_hi, nvlim);                 // the light ray enters at tau = exit
+    return !q.ok ? SH_UNSURE : miss ? SH_MISS : clean ? v : SH_UNSURE;
+}
+
+// plane: pd = n.P + d (float64, then rounded); tau = -pd / (w.n)
+__device__ __forceinline__ int sh_plane(float n0, float n1, float n2, float pd, float w0, float w1, float w2, float nv, float nvlim) {
+    const float vn = fmaf(w0, n0, fmaf(w1, n1, w2 * n2));
+    const float ev = 2.5f * RT_RHO;                                 // |n|_1 <= 1.74, plus the rounding of n and the dot product
+    const bool back = vn < -ev;                                     // the light ray sees the back: one-sided (InfinitePlane.py:83)
+    const bool facing = vn > ev;
+    const float rp = __builtin_amdgcn_rcpf(vn + ev), rm = __builtin_amdgcn_rcpf(vn - ev);   // 1 ulp; covered by the 7e-7 below
+    const float num = -pd, nu = num * (1.0f + 4.8e-7f), nd = num * (1.0f - 4.8e-7f);
+    const bool pos = num >= 0.0f;
+    float lo = pos ? nd * rp : nu * rm, hi = pos ? nu * rm : nd * rp;
+    lo -= fabsf(lo) * 7e-7f;
+    hi += fabsf(hi) * 7e-7f;
+    const bool beyond = lo > nv + (nv - nvlim);                     // plane beyond the sample (t < 0 from the light)
+    const int v = sh_classify(lo, hi, nvlim);
+    return back ? SH_MISS : !facing ? SH_UNSURE : beyond ? SH_MISS : v;
+}
+
+// Whole-pair verdict for a plane, from the box [cB - h, cB + h] of all sample origins (relative to P):
+// 1 = every ray of the pair misses it, 2 = it is P's own surface for every ray, 0 = decide per ray.
+#define RT_PLANE_EVAL 0u
+#define RT_PLANE_MISS 1u
+#define RT_PLANE_ATP 2u
+__device__ __forceinline__ uint32_t sh_plane_pair(float n0, float n1, float n2, float pd, float cB0, float cB1, float cB2,
+                                                  float h0, float h1, float h2) {
+    const float smax = (fabsf(cB0) + fabsf(cB1) + fabsf(cB2)) + (h0 + h1 + h2);      // >= |s| for every sample s
+    const float sc = fmaf(cB0, n0, fmaf(cB1, n1, cB2 * n2));
+    const float sh = fabsf(n0) * h0 + fabsf(n1) * h1 + fabsf(n2) * h2;
+    const float thr = 1e-5f * smax;                                  // float32 rounding of s.n is ~1e-6 smax
+    const float a = sc - sh, b = sc + sh;                            // s.n in [a, b];  w.n = s.n / |s|
+    if (!(smax < 1e30f)) return RT_PLANE_EVAL;
+    if (b < -thr) return RT_PLANE_MISS;                              // every light ray sees the back
+    if (a > thr && pd > 2e-6f) return RT_PLANE_MISS;                 // tau = -pd / (w.n) < -pd <= -2e-6: behind P
+    if (a > 1e-3f * smax && fabsf(pd) < 1e-10f) return RT_PLANE_ATP; // |tau| < 1e-10 / 1e-3
+    return RT_PLANE_EVAL;
 }
 
 // ---------------------------------------------------------------------------------------------
 // beam traversal: all points  lambda * s,  s in [cB - h, cB + h], lambda in [0, 1]  (P at the origin)
 // ---------------------------------------------------------------------------------------------
-// keep the part of [l0, l1] where  lambda * coef <= rhs
-__device__ __forceinline__ void clip_le(float &l0, float &l1, float coef, float rhs) {
-    if (coef > 0.0f) l1 = fminf(l1, rhs / coef);
-    else if (coef < 0.0f) l0 = fmaxf(l0, rhs / coef);
-    else if (rhs < 0.0f) l1 = -1.0f;                 // 0 <= rhs fails: empty
+// keep the part of [l0, l1] where  lambda * coef <= rhs.  icoef = 1 / coef to 1 ulp (anything when coef == 0);
+// the new bound is rounded outward, the interval only ever comes out too large
+__device__ __forceinline__ void clip_mul(float &l0, float &l1, float coef, float icoef, float rhs) {
+    const float t = rhs * icoef, w = fabsf(t) * RT_2M20;
+    l1 = coef > 0.0f ? fminf(l1, t + w) : l1;        // fminf / fmaxf drop a NaN t (0 * inf)
+    l0 = coef < 0.0f ? fmaxf(l0, t - w) : l0;
+    l1 = (coef == 0.0f && rhs < 0.0f) ? -1.0f : l1;  // 0 <= rhs fails: empty
 }
-__device__ __forceinline__ void clip_ge(float &l0, float &l1, float coef, float rhs) { clip_le(l0, l1, -coef, -rhs); }
 
 struct BeamStack {           // LDS columns, one entry per tree level
     uint2 *a;                // (node, lambda0 bits)
@@ -142,32 +177,36 @@ __device__ __forceinline__ float sel3(uint32_t ax, float v0, float v1, float v2)
 
 // returns units used | box mask << 8 (RT_META_OVERFLOW when the units do not suffice).  c* / h*: centre and half
 // size of the box of all sample origins, relative to P.  out: the pair record's RT_CUNITS candidate units.
+// Everything here is a conservative float32 filter; the absolute slack E covers the rounding of P, of the cut
+// planes / leaf records and of the differences (<= 6 Kp 2^-24 in all), the candidates it lets through are
+// re-expressed from float64.
 template <int STRIDE>
 __device__ __forceinline__ uint32_t beam_collect(const DScene &S, const FastScene &F, BeamStack stk, d3 P, float cB0, float cB1,
                                                  float cB2, float h0, float h1, float h2, float4 *out) {
     const float Pf0 = (float)P.x, Pf1 = (float)P.y, Pf2 = (float)P.z;
-    const float Pl0 = (float)(P.x - (double)Pf0), Pl1 = (float)(P.y - (double)Pf1), Pl2 = (float)(P.z - (double)Pf2);
     const float Kp = fmaxf(fmaxf(fabsf(Pf0), fabsf(Pf1)), fmaxf(fabsf(Pf2), F.extent));
-    const float E = Kp * RT_2M19 + 2e-6f;            // absolute slack on every plane position (rounding of cut, P, and 1e-6 offsets)
+    const float E = Kp * RT_2M19 + 2e-6f;            // absolute slack on every plane position (and the 1e-6 offsets)
     const float L0 = cB0 - h0, L1 = cB1 - h1, L2 = cB2 - h2, U0 = cB0 + h0, U1 = cB1 + h1, U2 = cB2 + h2;
+    const float iL0 = __builtin_amdgcn_rcpf(L0), iL1 = __builtin_amdgcn_rcpf(L1), iL2 = __builtin_amdgcn_rcpf(L2);
+    const float iU0 = __builtin_amdgcn_rcpf(U0), iU1 = __builtin_amdgcn_rcpf(U1), iU2 = __builtin_amdgcn_rcpf(U2);
     // the beam also lies inside the cone with apex P, axis cB and half-angle tan = |h| / |cB| (used for spheres)
     const float cl2 = fmaf(cB0, cB0, fmaf(cB1, cB1, cB2 * cB2));
-    const float icl = 1.0f / sqrtf(cl2);
-    const float ax0 = cB0 * icl, ax1 = cB1 * icl, ax2 = cB2 * icl;
-    const float kt = sqrtf(fmaf(h0, h0, fmaf(h1, h1, h2 * h2))) * icl * 1.0001f;      // tan(half angle), rounded up
+    const float icl = __builtin_amdgcn_rsqf(cl2);
+    const float ax0 = cB0 * icl, ax1 = cB1 * icl, ax2 = cB2 * icl;                    // |ax| = 1 +- 3e-7
+    const float kt = __builtin_amdgcn_sqrtf(fmaf(h0, h0, fmaf(h1, h1, h2 * h2))) * icl * 1.0001f;   // tan(half angle), rounded up
     const float ax_len = cl2 * icl;
     float l0 = 0.0f, l1 = 1.0f;
     // root box relative to P
-    clip_ge(l0, l1, U0, (F.root_lo[0] - Pf0) - Pl0 - E); clip_le(l0, l1, L0, (F.root_hi[0] - Pf0) - Pl0 + E);
-    clip_ge(l0, l1, U1, (F.root_lo[1] - Pf1) - Pl1 - E); clip_le(l0, l1, L1, (F.root_hi[1] - Pf1) - Pl1 + E);
-    clip_ge(l0, l1, U2, (F.root_lo[2] - Pf2) - Pl2 - E); clip_le(l0, l1, L2, (F.root_hi[2] - Pf2) - Pl2 + E);
+    clip_mul(l0, l1, -U0, -iU0, -((F.root_lo[0] - Pf0) - E)); clip_mul(l0, l1, L0, iL0, (F.root_hi[0] - Pf0) + E);
+    clip_mul(l0, l1, -U1, -iU1, -((F.root_lo[1] - Pf1) - E)); clip_mul(l0, l1, L1, iL1, (F.root_hi[1] - Pf1) + E);
+    clip_mul(l0, l1, -U2, -iU2, -((F.root_lo[2] - Pf2) - E)); clip_mul(l0, l1, L2, iL2, (F.root_hi[2] - Pf2) + E);
     uint32_t n = 0, nu = 0, boxmask = 0;             // candidates, units used, which units start a box
     uint32_t ids[RT_CMAX];                           // registers (static indices only): the pair's candidates so far
 #pragma unroll
     for (uint32_t j = 0; j < RT_CMAX; ++j) ids[j] = 0xffffffffu;
     if (!(l0 <= l1)) return 0;
-    // One loop, one memory access per trip: either a node step or a leaf entry.  Lanes of a wave sit at different
-    // places of their own traversals; a flat loop costs the longest single traversal, not the sum of the longest phases.
+    // One memory access per trip: a node step or a leaf entry.  The common trip (a leaf entry the beam's box
+    // does not touch) is a 32-byte load, 13 additions and 6 compares.
     const uint32_t NONE = 0xffffffffu;
     uint32_t node = 0, e = 0, e_end = 0;
     int sp = 0;
@@ -178,31 +217,31 @@ __device__ __forceinline__ uint32_t beam_collect(const DScene &S, const FastScen
             const LeafF lf = F.leaves[e];
             ++e;
             const uint32_t kind = lf.pk & 3u, prim = lf.pk >> 2;
-            float plo0, plo1, plo2, phi0, phi1, phi2;
-            bool in_cone = true;
-            if (kind == 1u) {
-                const float c0 = (lf.x - Pf0) + (lf.lx - Pl0), c1 = (lf.y - Pf1) + (lf.ly - Pl1), c2 = (lf.z - Pf2) + (lf.lz - Pl2);
-                plo0 = c0 - lf.r; plo1 = c1 - lf.r; plo2 = c2 - lf.r;
-                phi0 = c0 + lf.r; phi1 = c1 + lf.r; phi2 = c2 + lf.r;
-                // sphere against the cone: distance to the axis <= r (1 + tan) + axial position * tan (conservative)
+            const bool sph = kind == 1u;             // sphere {centre, r, (low parts)}; box {lo, -, hi}
+            const float rr = sph ? lf.r : 0.0f;
+            const float c0 = lf.x - Pf0, c1 = lf.y - Pf1, c2 = lf.z - Pf2;
+            const float d0 = sph ? c0 : lf.lx - Pf0, d1 = sph ? c1 : lf.ly - Pf1, d2 = sph ? c2 : lf.lz - Pf2;
+            const bool touch = !(c0 - rr > bhi0) && !(d0 + rr < blo0) && !(c1 - rr > bhi1) && !(d1 + rr < blo1) &&
+                               !(c2 - rr > bhi2) && !(d2 + rr < blo2);
+            if (!touch) continue;
+            if (sph) {
+                // sphere against the cone: distance to the axis <= r (1 + tan) + axial position * tan (conservative).
+                // The distance comes from the cross product: its error is ~1e-7 |c|, inside the 2e-6 |c| below.
                 const float ta = fmaf(c0, ax0, fmaf(c1, ax1, c2 * ax2));
-                const float cc = fmaf(c0, c0, fmaf(c1, c1, c2 * c2));
-                const float dp2 = fmaxf(cc - ta * ta, 0.0f);
-                const float lim = fmaf(lf.r, 1.0f + kt, fmaxf(ta, 0.0f) * kt) + E + 2e-6f * sqrtf(cc);
-                in_cone = !(dp2 > lim * lim * 1.0001f) && !(ta < -(lf.r + E)) && !(ta > ax_len * (1.0f + kt) + lf.r + E);
-            } else {
-                plo0 = (lf.x - Pf0) - Pl0; plo1 = (lf.y - Pf1) - Pl1; plo2 = (lf.z - Pf2) - Pl2;
-                phi0 = (lf.lx - Pf0) - Pl0; phi1 = (lf.ly - Pf1) - Pl1; phi2 = (lf.lz - Pf2) - Pl2;
+                const float k0 = fmaf(c1, ax2, -(c2 * ax1)), k1 = fmaf(c2, ax0, -(c0 * ax2)), k2 = fmaf(c0, ax1, -(c1 * ax0));
+                const float dp2 = fmaf(k0, k0, fmaf(k1, k1, k2 * k2));
+                const float cn = (fabsf(c0) + fabsf(c1)) + fabsf(c2);                 // >= |c|
+                const float lim = fmaf(lf.r, 1.0f + kt, fmaxf(ta, 0.0f) * kt) + E + 2e-6f * cn;
+                const bool in_cone = !(dp2 > lim * lim * 1.0001f) && !(ta < -(lf.r + E)) && !(ta > ax_len * (1.0f + kt) + lf.r + E);
+                if (!in_cone) continue;
             }
-            const bool touch = !(plo0 > bhi0) && !(phi0 < blo0) && !(plo1 > bhi1) && !(phi1 < blo1) && !(plo2 > bhi2) && !(phi2 < blo2);
-            if (!touch || !in_cone) continue;
             bool seen = false;                       // the same primitive is listed in several leaves
 #pragma unroll
             for (uint32_t j = 0; j < RT_CMAX; ++j) seen = seen || (j < n && ids[j] == prim);
             if (seen) continue;
             if (nu + kind > RT_CUNITS) return RT_META_OVERFLOW;       // kind == units needed (sphere 1, box 2)
             const DPrim *pr = S.prims + prim;
-            if (kind == 1u) {
+            if (sph) {
                 const double dx = pr->a[0] - P.x, dy = pr->a[1] - P.y, dz = pr->a[2] - P.z;
                 out[nu] = make_float4((float)dx, (float)dy, (float)dz, (float)(((dx * dx + dy * dy) + dz * dz) - pr->b[0]));
                 nu += 1;
@@ -240,10 +279,11 @@ __device__ __forceinline__ uint32_t beam_collect(const DScene &S, const FastScen
             continue;
         }
         const uint32_t ax = nd.b & 3u;
-        const float cut = (__uint_as_float(nd.a) - sel3(ax, Pf0, Pf1, Pf2)) - sel3(ax, Pl0, Pl1, Pl2);
+        const float cut = __uint_as_float(nd.a) - sel3(ax, Pf0, Pf1, Pf2);
+        const float La = sel3(ax, L0, L1, L2), Ua = sel3(ax, U0, U1, U2), iLa = sel3(ax, iL0, iL1, iL2), iUa = sel3(ax, iU0, iU1, iU2);
         float a0 = l0, a1 = l1, b0 = l0, b1 = l1;
-        clip_le(a0, a1, sel3(ax, L0, L1, L2), cut + E);      // left child: some beam point with x <= cut
-        clip_ge(b0, b1, sel3(ax, U0, U1, U2), cut - E);      // right child
+        clip_mul(a0, a1, La, iLa, cut + E);          // left child: some beam point with x <= cut
+        clip_mul(b0, b1, -Ua, -iUa, -(cut - E));     // right child: some beam point with x >= cut
         const bool goL = a0 <= a1, goR = b0 <= b1;
         if (goL && goR) {
             stk.a[sp * STRIDE] = make_uint2(nd.b >> 2, __float_as_uint(b0));
