@@ -43,6 +43,8 @@ struct FrameCtl {
     uint32_t overflow;
     uint32_t pad;
     unsigned long long reflect_rays, transmit_rays, primary_rays;
+    uint32_t n_listed[RT_MAX_LEVELS + 2];   // diagnostics: pairs that needed the per-ray filter / rays that needed
+    uint32_t n_queued[RT_MAX_LEVELS + 2];   // the float64 queue, per level (copied by k_shade)
 };
 
 struct RayQ {            // SoA ray queue in HBM
@@ -320,82 +322,160 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_setup(DScene S, LevelParams
     }
 }
 
-// beam path: float32 header + candidate list of every (hit, shadow light) pair (rt_shadow.hpp).  The basis is
-// computed in float32 from the float64 difference light - P; its error is part of the direction-error budget
-// RT_RHO of the per-ray predicates.  Pairs whose basis is numerically delicate are marked "overflow": all their
-// rays are then decided by the float64 path.
+// beam path: one lane per (hit, shadow light) pair (rt_shadow.hpp).  The basis is computed in float32 from the
+// float64 difference light - P; its error is part of the direction-error budget RT_RHO of the per-ray predicates.
+// A pair ends in one of three ways:
+//   decided as a whole (every ray lit / every ray unlit): only pair_slot[pair] is written - umbra, fully lit
+//     surfaces and P's own sphere on either side of the terminator never reach the per-ray kernel;
+//   listed: header + candidate units go to rec[pair], the pair gets a slot in bb.list (wave-aggregated append);
+//   numerically delicate basis / too many candidates: listed with the overflow mark, all its rays go to the
+//     float64 queue.
 __global__ void __launch_bounds__(RT_BLOCK) k_beam_setup(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb, BeamBuf bb,
                                                          FrameCtl *ctl) {
     extern __shared__ uint2 lds_stack[];
+    __shared__ uint32_t lbuf_all[(RT_BLOCK / 64) * 128];
     if (ctl->overflow) return;
     const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
     const uint32_t nsl = (uint32_t)S.n_shadow_lights;
     const uint32_t total = n_hits * nsl;           // < 2^32: checked on the host
+    const int lane = threadIdx.x & 63;
+    // listed pairs are parked in a wave-private LDS buffer and get their slots 64 at a time (one returning
+    // atomic on the list counter per 64 pairs; see k_shadow_beam)
+    uint32_t *lbuf = lbuf_all + (threadIdx.x >> 6) * 128;
+    uint32_t ln = 0u;
     ChunkWalk walk(total);
     uint64_t first;
     while (walk.next(first)) {
         const uint32_t seg = (uint32_t)first + threadIdx.x;
-        if (seg >= total) continue;
-        const uint32_t h = seg / nsl, ml = seg - h * nsl;
-        const uint32_t r = hb.list[h];
-        const int m = S.shadow_lights[ml];
-        const d3 P = mk3(hb.px[r], hb.py[r], hb.pz[r]);
-        const DLight &Lt = S.lights[m];
-        const d3 dl = ld3(Lt.pos) - P;
-        float4 *rec = bb.rec + (uint64_t)seg * RT_PAIR_UNITS;
-        // D = -(light - P)/|light - P|  (Light.py:81: light_direction = -L)
-        const float e0 = (float)dl.x, e1 = (float)dl.y, e2 = (float)dl.z;
-        const float il = 1.0f / sqrtf(fmaf(e0, e0, fmaf(e1, e1, e2 * e2)));
-        const float D0 = -e0 * il, D1 = -e1 * il, D2 = -e2 * il;
-        // util.get_orthonormal_vector: the branch is taken on the float64 value of D.z (Q7)
-        const double az = fabs(dl.z), an = fabs(dl.x) + fabs(dl.y) + az;
-        bool delicate = !(an > 0.0) || !(an < 1e7) || !ray_is_tame(P, dl);
-        float u0 = 1.0f, u1 = 1.0f, u2 = 0.0f;
-        if (dl.z != 0.0) {
-            if (az < 1e-280 * an || fabsf(D2) < 1e-12f) delicate = true;   // D.z would underflow, or (1,1,u3) overflows float32
-            u2 = -(D0 + D1) / D2;
-        }
-        const float iu = 1.0f / sqrtf(2.0f + u2 * u2);
-        u0 *= iu; u1 *= iu; u2 *= iu;
-        float r0 = u1 * D2 - u2 * D1, r1 = u2 * D0 - u0 * D2, r2 = u0 * D1 - u1 * D0;     // np.cross(up, D)
-        const float ir = 1.0f / (sqrtf(fmaf(r0, r0, fmaf(r1, r1, r2 * r2))) + 1e-6f);
-        r0 *= ir; r1 *= ir; r2 *= ir;
-        const float radius = (float)Lt.radius;
-        const float g = radius / (float)lp.sh_rays;
-        const float c0 = (radius - g) * 0.5f;
-        const float q00 = e0 + c0 * (u0 - r0), q01 = e1 + c0 * (u1 - r1), q02 = e2 + c0 * (u2 - r2);
-        float pd[RT_PMAX];
+        const bool valid = seg < total;
+        bool listed = false;
+        if (valid) {
+            const uint32_t h = seg / nsl, ml = seg - h * nsl;
+            const uint32_t r = hb.list[h];
+            const int m = S.shadow_lights[ml];
+            const d3 P = mk3(hb.px[r], hb.py[r], hb.pz[r]);
+            const DLight &Lt = S.lights[m];
+            const d3 dl = ld3(Lt.pos) - P;
+            float4 *rec = bb.rec + (uint64_t)seg * RT_PAIR_UNITS;
+            // D = -(light - P)/|light - P|  (Light.py:81: light_direction = -L)
+            const float e0 = (float)dl.x, e1 = (float)dl.y, e2 = (float)dl.z;
+            const float il = 1.0f / sqrtf(fmaf(e0, e0, fmaf(e1, e1, e2 * e2)));
+            const float D0 = -e0 * il, D1 = -e1 * il, D2 = -e2 * il;
+            // util.get_orthonormal_vector: the branch is taken on the float64 value of D.z (Q7)
+            const double az = fabs(dl.z), an = fabs(dl.x) + fabs(dl.y) + az;
+            bool delicate = !(an > 0.0) || !(an < 1e7) || !ray_is_tame(P, dl);
+            float u0 = 1.0f, u1 = 1.0f, u2 = 0.0f;
+            if (dl.z != 0.0) {
+                if (az < 1e-280 * an || fabsf(D2) < 1e-12f) delicate = true;   // D.z would underflow, or (1,1,u3) overflows float32
+                u2 = -(D0 + D1) / D2;
+            }
+            const float iu = 1.0f / sqrtf(2.0f + u2 * u2);
+            u0 *= iu; u1 *= iu; u2 *= iu;
+            float r0 = u1 * D2 - u2 * D1, r1 = u2 * D0 - u0 * D2, r2 = u0 * D1 - u1 * D0;     // np.cross(up, D)
+            const float ir = 1.0f / (sqrtf(fmaf(r0, r0, fmaf(r1, r1, r2 * r2))) + 1e-6f);
+            r0 *= ir; r1 *= ir; r2 *= ir;
+            const float radius = (float)Lt.radius;
+            const float g = radius / (float)lp.sh_rays;
+            const float c0 = (radius - g) * 0.5f;
+            const float q00 = e0 + c0 * (u0 - r0), q01 = e1 + c0 * (u1 - r1), q02 = e2 + c0 * (u2 - r2);
+            float pd[RT_PMAX];
 #pragma unroll
-        for (int k = 0; k < RT_PMAX; ++k) {
-            float v = 0.0f;
-            if (k < S.n_planes) v = (float)(dot3(ld3(S.planes[k].n), P) + S.planes[k].d);
-            pd[k] = v;
-        }
-        rec[0] = make_float4(q00, q01, q02, g);
-        rec[2] = make_float4(r0, r1, r2, __uint_as_float(q.gpix[r]));
-        rec[3] = make_float4(pd[0], pd[1], pd[2], __uint_as_float(q.path[r]));
-        // box of every sample origin of the pair, relative to P: grid points a,b in [0,s-1] and the
-        // component-wise deviations of Light.py:277-279 (|u| <= g on each of up and right)
-        const float sm1 = (float)(lp.sh_rays - 1);
-        const float cB0 = q00 + 0.5f * sm1 * g * (r0 - u0), cB1 = q01 + 0.5f * sm1 * g * (r1 - u1), cB2 = q02 + 0.5f * sm1 * g * (r2 - u2);
-        float h0 = (0.5f * sm1 + 1.0f) * g * (fabsf(u0) + fabsf(r0)), h1 = (0.5f * sm1 + 1.0f) * g * (fabsf(u1) + fabsf(r1)),
-              h2 = (0.5f * sm1 + 1.0f) * g * (fabsf(u2) + fabsf(r2));
-        h0 = fmaf(RT_2M18, fabsf(cB0) + h0, h0) + 1e-5f;
-        h1 = fmaf(RT_2M18, fabsf(cB1) + h1, h1) + 1e-5f;
-        h2 = fmaf(RT_2M18, fabsf(cB2) + h2, h2) + 1e-5f;
-        BeamStack bs;
-        bs.a = lds_stack + threadIdx.x;
-        bs.b = (float *)(lds_stack + (size_t)F.depth * RT_BLOCK) + threadIdx.x;
-        uint32_t nc = RT_META_OVERFLOW;
-        if (!delicate && (lp.flags & 0x100)) nc = 0;   // timing experiment only
-        else if (!delicate) nc = beam_collect<RT_BLOCK>(S, F, bs, P, cB0, cB1, cB2, h0, h1, h2, rec + 4);
-        uint32_t pcls = 0;                             // whole-pair verdicts of the planes
+            for (int k = 0; k < RT_PMAX; ++k) {
+                float v = 0.0f;
+                if (k < S.n_planes) v = (float)(dot3(ld3(S.planes[k].n), P) + S.planes[k].d);
+                pd[k] = v;
+            }
+            // the header leaves before the traversal (registers): wasted on pairs decided as a whole, 64 B each
+            rec[0] = make_float4(q00, q01, q02, g);
+            rec[1] = make_float4(u0, u1, u2, 0.0f);
+            rec[2] = make_float4(r0, r1, r2, __uint_as_float(q.gpix[r]));
+            rec[3] = make_float4(pd[0], pd[1], pd[2], __uint_as_float(q.path[r]));
+            // box of every sample origin of the pair, relative to P: grid points a,b in [0,s-1] and the
+            // component-wise deviations of Light.py:277-279 (|u| <= g on each of up and right)
+            const float sm1 = (float)(lp.sh_rays - 1);
+            const float cB0 = q00 + 0.5f * sm1 * g * (r0 - u0), cB1 = q01 + 0.5f * sm1 * g * (r1 - u1), cB2 = q02 + 0.5f * sm1 * g * (r2 - u2);
+            float h0 = (0.5f * sm1 + 1.0f) * g * (fabsf(u0) + fabsf(r0)), h1 = (0.5f * sm1 + 1.0f) * g * (fabsf(u1) + fabsf(r1)),
+                  h2 = (0.5f * sm1 + 1.0f) * g * (fabsf(u2) + fabsf(r2));
+            h0 = fmaf(RT_2M18, fabsf(cB0) + h0, h0) + 1e-5f;
+            h1 = fmaf(RT_2M18, fabsf(cB1) + h1, h1) + 1e-5f;
+            h2 = fmaf(RT_2M18, fabsf(cB2) + h2, h2) + 1e-5f;
+            BeamStack bs;
+            bs.a = lds_stack + threadIdx.x;
+            bs.b = (float *)(lds_stack + (size_t)F.depth * RT_BLOCK) + threadIdx.x;
+            uint32_t pcls = 0, n_eval = 0, n_atp = 0;      // whole-pair verdicts of the planes
 #pragma unroll
-        for (int k = 0; k < RT_PMAX; ++k)
-            if (k < S.n_planes)
-                pcls |= sh_plane_pair((float)S.planes[k].n[0], (float)S.planes[k].n[1], (float)S.planes[k].n[2], pd[k], cB0, cB1, cB2,
-                                      h0, h1, h2) << (2 * k);
-        rec[1] = make_float4(u0, u1, u2, __uint_as_float(nc | ((uint32_t)m << 16) | (pcls << 24)));
+            for (int k = 0; k < RT_PMAX; ++k)
+                if (k < S.n_planes) {
+                    const uint32_t c = sh_plane_pair((float)S.planes[k].n[0], (float)S.planes[k].n[1], (float)S.planes[k].n[2], pd[k],
+                                                     cB0, cB1, cB2, h0, h1, h2);
+                    pcls |= c << (2 * k);
+                    n_eval += c == RT_PLANE_EVAL;
+                    n_atp += c == RT_PLANE_ATP;
+                }
+            BeamOut bo;
+            bo.nu = 0; bo.boxmask = 0; bo.overflow = true; bo.occ_all = false; bo.atp_all = false;
+            if (!delicate) {
+                if (lp.flags & 0x100) bo.overflow = false;   // timing experiment only
+                else {
+                    LightQuad Q;
+                    Q.u0 = u0; Q.u1 = u1; Q.u2 = u2; Q.r0 = r0; Q.r1 = r1; Q.r2 = r2;
+                    const float ur = fabsf(u0 * r0) + fabsf(u1 * r1) + fabsf(u2 * r2);
+                    Q.aq = (0.5f * sm1 * g + g * (1.0f + ur)) * 1.0001f + 1e-5f;
+                    Q.ja = (g * ((fabsf(u0) + fabsf(r0)) * fabsf(D0) + (fabsf(u1) + fabsf(r1)) * fabsf(D1) + (fabsf(u2) + fabsf(r2)) * fabsf(D2))) * 1.0001f + 1e-5f;
+                    bo = beam_collect<RT_BLOCK>(S, F, bs, P, cB0, cB1, cB2, h0, h1, h2, Q, rec + 4);
+                }
+            }
+            // every |sample - P| inside the per-ray filter's range (k_shadow_beam: 1e-4 < nv < 1e7)
+            const float sc = sqrtf(fmaf(cB0, cB0, fmaf(cB1, cB1, cB2 * cB2))), sh = sqrtf(fmaf(h0, h0, fmaf(h1, h1, h2 * h2)));
+            const bool range_ok = sc - sh > 1e-3f && sc + sh < 1e6f;
+            uint32_t whole = 0;                             // RT_PAIR_LIT / RT_PAIR_UNLIT when decided
+            if (!bo.overflow && range_ok) {
+                if (bo.occ_all) whole = RT_PAIR_UNLIT;
+                else if (bo.nu == 0 && n_eval == 0) whole = (n_atp + (bo.atp_all ? 1u : 0u)) > 0 ? RT_PAIR_LIT : RT_PAIR_UNLIT;
+            }
+            if (whole) bb.pair_slot[seg] = whole;
+            else {
+                listed = true;
+                const uint32_t nc = bo.overflow ? RT_META_OVERFLOW : (bo.nu | (bo.boxmask << 8));
+                reinterpret_cast<uint32_t *>(rec + 1)[3] = nc | ((uint32_t)m << 16) | (pcls << 24) | (bo.atp_all ? 1u << 30 : 0u);
+            }
+        }
+        // listed pairs -> wave buffer -> bb.list
+        const unsigned long long lm = __ballot(listed);
+        if (lm) {
+            if (listed) lbuf[ln + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull))] = seg;
+            ln += (uint32_t)__popcll(lm);
+            if (ln >= 64u) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&bb.queue_n[1], 64u);
+                base = __shfl(base, 0);
+                const uint32_t v = lbuf[lane], v2 = lbuf[64 + lane];
+                bb.list[base + (uint32_t)lane] = v;
+                bb.pair_slot[v] = base + (uint32_t)lane;
+                ln -= 64u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                if ((uint32_t)lane < ln) lbuf[lane] = v2;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    if (ln) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&bb.queue_n[1], ln);
+        base = __shfl(base, 0);
+        if ((uint32_t)lane < ln) {
+            const uint32_t v = lbuf[lane];
+            bb.list[base + (uint32_t)lane] = v;
+            bb.pair_slot[v] = base + (uint32_t)lane;
+        }
     }
 }
 
@@ -479,43 +559,52 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene S, FastScene F, Leve
     }
 }
 
-// one lane per soft-shadow ray, float32 filtered predicates on the pair's candidate list (rt_shadow.hpp);
-// undecided rays go to the queue.  A chunk of RT_BLOCK lanes holds lp.spb whole pairs; their records
-// (lp.spb * 192 contiguous bytes) are staged through LDS with 16-byte loads issued one chunk ahead and parked
-// in registers while the current chunk is classified - the HBM round trip of a chunk overlaps the arithmetic
-// of the previous one.
-// Staging is per WAVE: the <= 9 pairs a wave's 64 lanes belong to (s*s >= 9) are <= 108 units = two 16-byte loads
-// per lane into the wave's own LDS slice, so no workgroup barrier is needed (a wave's DS operations execute in order).
-// The lane -> (pair, sample) map is the same in every chunk, so is the wave's segment structure for the lit counts.
+// one lane per soft-shadow ray of the LISTED pairs (k_beam_setup), float32 filtered predicates on the pair's
+// candidate list (rt_shadow.hpp); undecided rays go to the queue.  A chunk of RT_BLOCK lanes holds lp.spb whole
+// pairs = consecutive slots of bb.list.  Staging is per WAVE: the <= 9 pairs a wave's 64 lanes belong to
+// (s*s >= 9) are <= 108 units = two 16-byte loads per lane into the wave's own LDS slice, so no workgroup barrier
+// is needed (a wave's DS operations execute in order).  Software pipeline, per wave: while chunk i is classified,
+// the records of chunk i+1 are in flight (parked in registers until the top of the next iteration) and so are
+// the pair numbers of chunk i+2.
+// The lane -> (pair, sample) map is the same in every chunk.
 #define RT_WAVE_UNITS 128
 __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams lp, HitBuf hb, BeamBuf bb, FrameCtl *ctl) {
     __shared__ float4 pair_lds_all[(RT_BLOCK / 64) * RT_WAVE_UNITS];
+    __shared__ unsigned long long qbuf_all[(RT_BLOCK / 64) * 128];
     if (ctl->overflow) return;
-    const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
+    const uint32_t NONE = 0xffffffffu;
     const uint32_t s = (uint32_t)lp.sh_rays, s2 = s * s;
-    const uint32_t nseg = n_hits * (uint32_t)S.n_shadow_lights;
-    const uint32_t nchunks = (nseg + lp.spb - 1) / lp.spb;
-    const uint32_t units = lp.spb * RT_PAIR_UNITS;
+    const uint32_t queue_cap = bb.queue_n[2];
+    const uint32_t nlist = min(bb.queue_n[1], min(ctl->n_hits[lp.level], lp.cap) * (uint32_t)S.n_shadow_lights);
+    const uint32_t nchunks = (nlist + lp.spb - 1) / lp.spb;
     ChunkWalk walk((uint64_t)nchunks * RT_BLOCK);
     uint64_t first;
     const int lane = threadIdx.x & 63;
-    const uint32_t wave0 = threadIdx.x & ~63u;
-    float4 *pair_lds = pair_lds_all + (threadIdx.x >> 6) * RT_WAVE_UNITS;
+    const uint32_t wave = threadIdx.x >> 6, wave0 = threadIdx.x & ~63u;
+    float4 *pair_lds = pair_lds_all + wave * RT_WAVE_UNITS;
+    // Undecided rays are parked in a wave-private LDS buffer and leave 64 at a time: ONE returning atomic on the
+    // queue counter per 64 rays.  (One per wave and chunk was the bottleneck of this kernel: returning atomics
+    // on a single address complete at ~30 ns each.)
+    unsigned long long *qbuf = qbuf_all + wave * 128;
+    uint32_t qn = 0u;
     const uint32_t sib = __umulhi(threadIdx.x, lp.magic_s2);          // pair within the chunk
     const uint32_t kk = threadIdx.x - sib * s2;                        // sample within the pair
     const uint32_t a = s == 1 ? kk : __umulhi(kk, lp.magic_s), b = kk - a * s;   // Light.py:265: jj = a, ii = b
     const float fa = (float)a, fb = (float)b;
-    // pairs of this wave: first .. last (within the chunk), their units
+    // pairs of this wave: first .. last (within the chunk); lane l < npw fetches the pair number of pair wp0 + l
     const uint32_t wp0 = __umulhi(wave0, lp.magic_s2);
     const uint32_t wp1 = min(__umulhi(wave0 + 63u, lp.magic_s2), lp.spb - 1u);
-    const uint32_t wunits = wp1 >= wp0 ? (wp1 - wp0 + 1u) * RT_PAIR_UNITS : 0u;      // <= RT_WAVE_UNITS (host checks s*s >= 9)
-    const uint32_t wbase = wp0 * RT_PAIR_UNITS;
+    const uint32_t npw = wp1 >= wp0 ? wp1 - wp0 + 1u : 0u;             // <= 9 (host checks s*s >= 9): <= RT_WAVE_UNITS units
+    const uint32_t mypair = sib < lp.spb ? sib - wp0 : 63u;            // lane 63 never fetches a pair number: NONE
     const float4 *rec = pair_lds + (sib < lp.spb ? (sib - wp0) * RT_PAIR_UNITS : 0u);
+    // staging: unit i of the wave's slice = unit i % 12 of its pair i / 12
+    const uint32_t i0u = (uint32_t)lane, i1u = (uint32_t)lane + 64u;
+    const uint32_t sp0 = i0u / RT_PAIR_UNITS, su0 = i0u - sp0 * RT_PAIR_UNITS, sp1 = i1u / RT_PAIR_UNITS, su1 = i1u - sp1 * RT_PAIR_UNITS;
+    const bool has0 = sp0 < npw, has1 = sp1 < npw;
     // Lit verdicts leave as one 64-bit ballot per wave and chunk (k_shade counts the bits of a pair).  No global
     // atomic or store sits in the steady-state loop - the wait for the staged loads at the top of an iteration
     // would otherwise also wait for them (one vmcnt) - : lane l of the wave parks the ballot of iteration
     // 64 w + l, and the wave stores 64 of them at once.
-    const uint32_t wave = threadIdx.x >> 6;
     unsigned long long keep = 0ull;
     uint32_t it = 0u, win_chunk = 0u;
     const uint32_t cstep = walk.step;
@@ -524,37 +613,49 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
         for (int c = 0; c < 3; ++c) pn[k][c] = k < S.n_planes ? (float)S.planes[k].n[c] : 0.0f;
     const uint32_t zkey = lp.seed * 0x85EBCA6Bu + kk;
     float4 st0 = make_float4(0, 0, 0, 0), st1 = st0;
-    const uint32_t i0u = (uint32_t)lane, i1u = (uint32_t)lane + 64u;
-#define RT_STAGE_LOAD(src_) do { if (i0u < wunits) st0 = (src_)[wbase + i0u]; if (i1u < wunits) st1 = (src_)[wbase + i1u]; } while (0)
-    bool have = walk.next(first);
-    uint32_t chunk = have ? (uint32_t)(first / RT_BLOCK) : 0u;
+#define RT_LOAD_PAIRNO(dst_, chunk_) do { const uint32_t sl_ = (chunk_) * lp.spb + wp0 + (uint32_t)lane; \
+        dst_ = ((uint32_t)lane < npw && sl_ < nlist) ? bb.list[sl_] : NONE; } while (0)
+#define RT_LOAD_RECS(pairno_) do { const uint32_t g0_ = __shfl((pairno_), (int)sp0), g1_ = __shfl((pairno_), (int)sp1); \
+        if (has0 && g0_ != NONE) st0 = bb.rec[(uint64_t)g0_ * RT_PAIR_UNITS + su0]; \
+        if (has1 && g1_ != NONE) st1 = bb.rec[(uint64_t)g1_ * RT_PAIR_UNITS + su1]; } while (0)
+    uint32_t cur = 0u, nxt = 0u, pno_cur = NONE, pno_nxt = NONE;
+    bool have = walk.next(first), have_n = false;
     if (have) {
-        const float4 *src = bb.rec + (uint64_t)chunk * units;
-        RT_STAGE_LOAD(src);
+        cur = (uint32_t)(first / RT_BLOCK);
+        RT_LOAD_PAIRNO(pno_cur, cur);
+        RT_LOAD_RECS(pno_cur);
+        have_n = walk.next(first);
+        if (have_n) {
+            nxt = (uint32_t)(first / RT_BLOCK);
+            RT_LOAD_PAIRNO(pno_nxt, nxt);
+        }
     }
     while (have) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // earlier reads of the slice are done (WAR)
         __builtin_amdgcn_wave_barrier();
-        if (i0u < wunits) pair_lds[i0u] = st0;
-        if (i1u < wunits) pair_lds[i1u] = st1;
+        if (has0) pair_lds[i0u] = st0;
+        if (has1) pair_lds[i1u] = st1;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const uint32_t cur = chunk;
-        have = walk.next(first);
-        if (have) {                                  // next chunk's records: in flight during the arithmetic below
-            chunk = (uint32_t)(first / RT_BLOCK);
-            const float4 *src = bb.rec + (uint64_t)chunk * units;
-            RT_STAGE_LOAD(src);
+        uint32_t n2 = 0u, pno_n2 = NONE;
+        bool have_n2 = false;
+        if (have_n) {                                // in flight during the arithmetic below
+            RT_LOAD_RECS(pno_nxt);
+            have_n2 = walk.next(first);
+            if (have_n2) {
+                n2 = (uint32_t)(first / RT_BLOCK);
+                RT_LOAD_PAIRNO(pno_n2, n2);
+            }
         }
-        const uint32_t seg = cur * lp.spb + sib;
-        const bool active = sib < lp.spb && seg < nseg;
+        const uint32_t seg = __shfl(pno_cur, (int)mypair);            // the lane's (hit, light) pair
+        const bool active = seg != NONE;
         bool lit = false, unsure = false;
-        if (active) {
+        if (active && !(lp.flags & 0x200)) {
             const float4 h0 = rec[0], h1 = rec[1], h2 = rec[2], h3 = rec[3];
             const float g = h0.w;
             const uint32_t meta = __float_as_uint(h1.w);
-            const uint32_t nu = meta & 0xffu, boxmask = (meta >> 8) & 0xffu;
+            const uint32_t nu = (lp.flags & 0x400) ? 0u : meta & 0xffu, boxmask = (meta >> 8) & 0xffu;
             if (nu == RT_META_OVERFLOW) unsure = true;
             else {
                 float j10 = 0, j11 = 0, j12 = 0, j20 = 0, j21 = 0, j22 = 0;   // Light.py:277-278: one deviation per component
@@ -579,9 +680,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
                 const float nvlim = nv - fmaf(nv, 4.0f * RT_RHO, 1e-5f);
                 w0 *= inv_nv; w1 *= inv_nv; w2 *= inv_nv;
                 int verdict = (!(nv > 1e-4f) || !(nv < 1e7f)) ? SH_UNSURE : 0;
-                int n_atp = 0;
+                int n_atp = (int)((meta >> 30) & 1u);                // P's own sphere, decided for the whole pair
                 const float pdk[RT_PMAX] = {h3.x, h3.y, h3.z};
-                const uint32_t pcls = meta >> 24;
+                const uint32_t pcls = (meta >> 24) & 0x3fu;
 #pragma unroll
                 for (int k = 0; k < RT_PMAX; ++k) {
                     if (k < S.n_planes) {
@@ -614,17 +715,28 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
                 else lit = n_atp > 0;
             }
         }
-        // undecided rays -> queue (one atomic per wave)
-        unsigned long long um = __ballot(unsure);
+        // undecided rays -> wave buffer -> queue
+        if (lp.flags & 0x800) unsure = false;       // timing experiment only
+        const unsigned long long um = __ballot(unsure);
         if (um) {
-            int qleader = __ffsll((long long)um) - 1;
-            uint32_t base = 0;
-            if (lane == qleader) base = atomicAdd(&bb.queue_n[0], (uint32_t)__popcll(um));
-            base = __shfl(base, qleader);
-            if (unsure) {
-                uint32_t at = base + (uint32_t)__popcll(um & ((1ull << lane) - 1ull));
-                if (at < bb.queue_n[1]) bb.queue[at] = (unsigned long long)seg * s2 + kk;
+            if (unsure) qbuf[qn + (uint32_t)__popcll(um & ((1ull << lane) - 1ull))] = (unsigned long long)seg * s2 + kk;
+            qn += (uint32_t)__popcll(um);
+            if (qn >= 64u) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&bb.queue_n[0], 64u);
+                base = __shfl(base, 0);
+                const unsigned long long v = qbuf[lane], v2 = qbuf[64 + lane];
+                if (base + (uint32_t)lane < queue_cap) bb.queue[base + (uint32_t)lane] = v;
                 else ctl->overflow = 1;             // frame is void; the host re-renders with a larger queue
+                qn -= 64u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                if ((uint32_t)lane < qn) qbuf[lane] = v2;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
             }
         }
         const unsigned long long lm = __ballot(lit);
@@ -632,8 +744,22 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
         if ((uint32_t)lane == (it & 63u)) keep = lm;
         ++it;
         if ((it & 63u) == 0u) bb.litbits[((uint64_t)win_chunk + (uint64_t)lane * cstep) * (RT_BLOCK / 64) + wave] = keep;
+        cur = nxt; pno_cur = pno_nxt; have = have_n;
+        nxt = n2; pno_nxt = pno_n2; have_n = have_n2;
     }
     if ((uint32_t)lane < (it & 63u)) bb.litbits[((uint64_t)win_chunk + (uint64_t)lane * cstep) * (RT_BLOCK / 64) + wave] = keep;
+    if (qn) {                                        // the rest of the wave's undecided rays
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&bb.queue_n[0], qn);
+        base = __shfl(base, 0);
+        if ((uint32_t)lane < qn) {
+            if (base + (uint32_t)lane < queue_cap) bb.queue[base + (uint32_t)lane] = qbuf[lane];
+            else ctl->overflow = 1;
+        }
+    }
 }
 
 // the rays the filter could not decide, in float64
@@ -642,7 +768,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_queue(DScene S, FastScene F
     extern __shared__ uint2 lds_stack[];
     uint2 *stk = lds_stack + threadIdx.x;
     if (ctl->overflow) return;
-    const uint32_t n = min(bb.queue_n[0], bb.queue_n[1]);
+    const uint32_t n = min(bb.queue_n[0], bb.queue_n[2]);
     const uint32_t s2 = (uint32_t)(lp.sh_rays * lp.sh_rays);
     ChunkWalk walk(n);
     uint64_t first;
@@ -656,8 +782,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_queue(DScene S, FastScene F
 
 // Phong shading + secondary-ray generation for every hit of the level
 __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, LevelParams lp, RayQ q, RayQ qn, HitBuf hb, FrameCtl *ctl,
-                                                    double *fb, const unsigned long long *litbits) {
+                                                    double *fb, const unsigned long long *litbits, const uint32_t *pair_slot, const uint32_t *queue_n) {
     if (ctl->overflow) return;
+    if (lp.beam && blockIdx.x == 0 && threadIdx.x == 0) { ctl->n_queued[lp.level] = queue_n[0]; ctl->n_listed[lp.level] = queue_n[1]; }
     const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
     const uint32_t nsl = (uint32_t)S.n_shadow_lights;
     const double s2 = (double)(lp.sh_rays * lp.sh_rays);
@@ -701,15 +828,20 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, LevelParams lp, Ra
                     uint64_t seg = (uint64_t)h * nsl + ml;
                     uint32_t cnt = hb.lit[seg];
                     hb.lit[seg] = 0;                                     // ready for the next level
-                    if (lp.beam) {                                       // + the filter's verdicts: lanes [lo, lo + s*s) of the pair's chunk
-                        const uint32_t chunk = (uint32_t)seg / lp.spb, sib = (uint32_t)seg - chunk * lp.spb;
-                        const uint32_t lo = sib * (uint32_t)(lp.sh_rays * lp.sh_rays), hi = lo + (uint32_t)(lp.sh_rays * lp.sh_rays);
-                        const unsigned long long *bits = litbits + (uint64_t)chunk * (RT_BLOCK / 64);
-                        for (uint32_t w = lo >> 6; w <= ((hi - 1u) >> 6); ++w) {
-                            const uint32_t b0 = w << 6;
-                            const uint32_t l = lo > b0 ? lo - b0 : 0u, u = hi < b0 + 64u ? hi - b0 : 64u;   // bit range [l, u) of word w
-                            const unsigned long long m = (u == 64u ? ~0ull : ((1ull << u) - 1ull)) & ~((1ull << l) - 1ull);
-                            cnt += (uint32_t)__popcll(bits[w] & m);
+                    if (lp.beam) {                                       // + the beam path's verdicts
+                        const uint32_t ps = pair_slot[seg];
+                        const uint32_t ss = (uint32_t)(lp.sh_rays * lp.sh_rays);
+                        if (ps == RT_PAIR_LIT) cnt += ss;
+                        else if (ps != RT_PAIR_UNLIT) {                  // listed: lanes [lo, lo + s*s) of the slot's chunk
+                            const uint32_t chunk = ps / lp.spb, sib = ps - chunk * lp.spb;
+                            const uint32_t lo = sib * ss, hi = lo + ss;
+                            const unsigned long long *bits = litbits + (uint64_t)chunk * (RT_BLOCK / 64);
+                            for (uint32_t w = lo >> 6; w <= ((hi - 1u) >> 6); ++w) {
+                                const uint32_t b0 = w << 6;
+                                const uint32_t l = lo > b0 ? lo - b0 : 0u, u = hi < b0 + 64u ? hi - b0 : 64u;   // bit range [l, u) of word w
+                                const unsigned long long m = (u == 64u ? ~0ull : ((1ull << u) - 1ull)) & ~((1ull << l) - 1ull);
+                                cnt += (uint32_t)__popcll(bits[w] & m);
+                            }
                         }
                     }
                     ml++;
@@ -1151,7 +1283,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
             HIP_C(hipFuncSetAttribute((const void *)&k_intersect<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow_queue, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup, hipFuncAttributeMaxDynamicSharedMemorySize, big - 4096));   // 2 KB of static LDS (list buffer)
             HIP_C(hipFuncSetAttribute((const void *)&k_intersect_only<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         }
         if (getenv("RT_AMD_DEBUG")) fprintf(stderr, "[rt_amd] kd view: ok=%d depth=%d lds=%zu B\n", ctx->F.ok, max_depth, ctx->lds_bytes);
@@ -1296,10 +1428,11 @@ static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
     BeamBuf &bb = ctx->beam;
     ctx->beam_queue_cap = (uint32_t)(cap < 0x7fffffffull ? cap : 0x7fffffffull);
     TRY_A(dalloc(ctx, &bb.rec, (nlit + RT_BLOCK) * RT_PAIR_UNITS));   // + one chunk of slack: staging reads whole chunks
-    TRY_A(dalloc(ctx, &bb.queue, (uint64_t)ctx->beam_queue_cap)); TRY_A(dalloc(ctx, &bb.queue_n, 2));
+    TRY_A(dalloc(ctx, &bb.queue, (uint64_t)ctx->beam_queue_cap)); TRY_A(dalloc(ctx, &bb.queue_n, 4));
     TRY_A(dalloc(ctx, &bb.litbits, (nlit + 1) * (RT_BLOCK / 64)));      // worst case one pair per chunk (s*s > RT_BLOCK / 2)
+    TRY_A(dalloc(ctx, &bb.list, nlit)); TRY_A(dalloc(ctx, &bb.pair_slot, nlit));
     {
-        uint32_t init[2] = {0u, ctx->beam_queue_cap};
+        uint32_t init[4] = {0u, 0u, ctx->beam_queue_cap, 0u};
         HIP_TRY(ctx, hipMemcpy(bb.queue_n, init, sizeof(init), hipMemcpyHostToDevice));
     }
     TRY_A(dalloc(ctx, &ctx->fb, slots * 3));
@@ -1411,7 +1544,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         PROF_MARK(e + 2);
         if (ctx->S.n_shadow_lights > 0) {
             if (beam) {
-                HIP_TRY(ctx, hipMemsetAsync(ctx->beam.queue_n, 0, sizeof(uint32_t), st));
+                HIP_TRY(ctx, hipMemsetAsync(ctx->beam.queue_n, 0, 2 * sizeof(uint32_t), st));
                 hipLaunchKernelGGL(k_beam_setup, dim3(ctx->g_beam_setup), block, ctx->lds_bytes * 3 / 2, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->beam, ctx->ctl);
                 hipLaunchKernelGGL(k_shadow_beam, dim3(ctx->g_beam), block, 0, st, ctx->S, lp, ctx->hb, ctx->beam, ctx->ctl);
                 hipLaunchKernelGGL(k_shadow_queue, dim3(ctx->g_queue), block, ctx->lds_bytes, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->seg, ctx->beam, ctx->ctl);
@@ -1423,7 +1556,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         }
         PROF_MARK(e + 3);
         PROF_MARK(e + 4);
-        hipLaunchKernelGGL(k_shade, dim3(ctx->g_shade), block, 0, st, ctx->S, lp, qc, qn, ctx->hb, ctx->ctl, ctx->fb, ctx->beam.litbits);
+        hipLaunchKernelGGL(k_shade, dim3(ctx->g_shade), block, 0, st, ctx->S, lp, qc, qn, ctx->hb, ctx->ctl, ctx->fb, ctx->beam.litbits, ctx->beam.pair_slot, ctx->beam.queue_n);
         PROF_MARK(e + 5);
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -1528,23 +1661,31 @@ extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
         }
     }
     if (getenv("RT_AMD_DEBUG") && ctx->beam.rec && c.n_hits[0] > 0) {
-        // histogram of candidate units over a slice of level-0 pairs (diagnostics only)
-        uint64_t nseg = (uint64_t)c.n_hits[0] * (uint64_t)ctx->S.n_shadow_lights;
-        uint64_t lo = nseg / 2, n = nseg - lo < 500000 ? nseg - lo : 500000;
-        std::vector<float4> h(n * RT_PAIR_UNITS);
-        if (n && hipMemcpy(h.data(), ctx->beam.rec + lo * RT_PAIR_UNITS, h.size() * sizeof(float4), hipMemcpyDeviceToHost) == hipSuccess) {
-            uint64_t hist[RT_CUNITS + 2] = {0};
-            for (uint64_t i = 0; i < n; ++i) {
+        // beam path diagnostics: per level, pairs / pairs that needed the per-ray filter / rays that needed float64
+        for (int l = 0; l <= ctx->last_rec && l < RT_MAX_LEVELS; ++l)
+            fprintf(stderr, "[rt_amd] level %d: %llu pairs, %u listed, %u rays queued\n", l,
+                    (unsigned long long)c.n_hits[l] * (unsigned long long)ctx->S.n_shadow_lights, c.n_listed[l], c.n_queued[l]);
+        // candidate units of the listed pairs of the LAST level (render with rec_max = 0 to see level 0)
+        uint32_t qn[4] = {0, 0, 0, 0};
+        (void)hipMemcpy(qn, ctx->beam.queue_n, sizeof(qn), hipMemcpyDeviceToHost);
+        uint32_t n = qn[1] < 200000u ? qn[1] : 200000u;
+        std::vector<uint32_t> lst(n);
+        if (n && hipMemcpy(lst.data(), ctx->beam.list, n * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess) {
+            uint64_t hist[RT_CUNITS + 2] = {0}, evalp = 0, base = 0;
+            for (uint32_t i = 0; i < n; ++i) {
+                float4 u1;
+                if (hipMemcpy(&u1, ctx->beam.rec + (uint64_t)lst[i] * RT_PAIR_UNITS + 1, sizeof(u1), hipMemcpyDeviceToHost) != hipSuccess) break;
                 uint32_t meta;
-                memcpy(&meta, &h[i * RT_PAIR_UNITS + 1].w, 4);
+                memcpy(&meta, &u1.w, 4);
                 uint32_t nu = meta & 0xff;
                 hist[nu > RT_CUNITS ? RT_CUNITS + 1 : nu]++;
+                evalp += ((meta >> 24) & 3u) == 0u;
+                base += (meta >> 30) & 1u;
+                if (i >= 20000) { n = i + 1; break; }
             }
-            fprintf(stderr, "[rt_amd] candidate units per pair over %llu pairs:", (unsigned long long)n);
+            fprintf(stderr, "[rt_amd] last level, %u listed pairs sampled: units", n);
             for (int k = 0; k <= RT_CUNITS + 1; ++k) fprintf(stderr, " %d:%.1f%%", k, 100.0 * hist[k] / n);
-            uint32_t qn[2] = {0, 0};
-            (void)hipMemcpy(qn, ctx->beam.queue_n, sizeof(qn), hipMemcpyDeviceToHost);
-            fprintf(stderr, "  | queue of the last level: %u\n", qn[0]);
+            fprintf(stderr, " | plane0 per ray %.1f%% | own sphere at P %.1f%%\n", 100.0 * evalp / n, 100.0 * base / n);
         }
     }
     if (c.overflow) {

@@ -43,9 +43,13 @@ struct CandF {               // decoded candidate
 struct BeamBuf {
     float4 *rec;             // [pair][RT_PAIR_UNITS]
     unsigned long long *queue;   // shadow-ray numbers g the filter could not decide
-    uint32_t *queue_n;       // [0] = entries appended, [1] = capacity
-    unsigned long long *litbits; // [chunk][wave]: which lanes' rays the filter found lit (every word written per level)
+    uint32_t *queue_n;       // [0] = queue entries appended, [1] = pairs listed, [2] = queue capacity
+    uint32_t *list;          // [slot] -> pair: the pairs whose rays need the per-ray filter, in no particular order
+    uint32_t *pair_slot;     // [pair] -> slot, or RT_PAIR_LIT / RT_PAIR_UNLIT when the whole pair is decided
+    unsigned long long *litbits; // [chunk of slots][wave]: which lanes' rays the filter found lit (every word written per level)
 };
+#define RT_PAIR_LIT 0xFFFFFFFFu
+#define RT_PAIR_UNLIT 0xFFFFFFFEu
 #define RT_META_OVERFLOW 0xFFu
 
 #define RT_T1 1e-6f          // the reference's EPSILON (Light.py:221)
@@ -70,6 +74,8 @@ __device__ __forceinline__ int sh_classify(float lo, float hi, float nvlim) {
 // tau_out = b + sqrt(D); for b < 0 the stable form is  -c / (|b| + sqrt(D)).
 __device__ __forceinline__ int sh_sphere(float a0, float a1, float a2, float c, float w0, float w1, float w2, float nvlim) {
     const float b = fmaf(w0, a0, fmaf(w1, a1, w2 * a2));
+    // clear miss, the common verdict: ed below is <= 1.1e-5 |a|^2 when D < 0 (then 0 <= c <= |a|^2)
+    if (fmaf(b, b, -c) < -1.5e-5f * fmaf(a0, a0, fmaf(a1, a1, a2 * a2))) return SH_MISS;
     const float eb = RT_2M20 * (fabsf(w0 * a0) + fabsf(w1 * a1) + fabsf(w2 * a2)) + RT_RHO * (fabsf(a0) + fabsf(a1) + fabsf(a2));
     const float disc = fmaf(b, b, -c);
     const float ed = fmaf(2.0f * fabsf(b), eb, eb * eb) + 4.8e-7f * (b * b + fabsf(c));
@@ -175,36 +181,67 @@ struct BeamStack {           // LDS columns, one entry per tree level
 
 __device__ __forceinline__ float sel3(uint32_t ax, float v0, float v1, float v2) { return ax == 0 ? v0 : (ax == 1 ? v1 : v2); }
 
-// returns units used | box mask << 8 (RT_META_OVERFLOW when the units do not suffice).  c* / h*: centre and half
-// size of the box of all sample origins, relative to P.  out: the pair record's RT_CUNITS candidate units.
-// Everything here is a conservative float32 filter; the absolute slack E covers the rounding of P, of the cut
-// planes / leaf records and of the differences (<= 6 Kp 2^-24 in all), the candidates it lets through are
-// re-expressed from float64.
+// The sample origins of a pair in the frame (up, right, axis = cB / |cB|; up, right are orthogonal to the axis):
+// |s.up|, |s.right| <= aq and |s.axis - |cB|| <= ja for every sample s, deviations of Light.py:277-279 included.
+struct LightQuad {
+    float u0, u1, u2, r0, r1, r2;
+    float aq, ja;
+};
+
+// Result of the beam traversal of one (hit, light) pair.
+struct BeamOut {
+    uint32_t nu, boxmask;    // candidate units written to out[], which of them start a box
+    bool overflow;           // the units do not suffice: every ray of the pair goes to the float64 queue
+    bool occ_all;            // one sphere occludes EVERY ray of the pair (traversal stopped there)
+    bool atp_all;            // P lies on a sphere that every ray of the pair leaves through P (not stored in out[])
+};
+
+// c* / h*: centre and half size of the box of all sample origins, relative to P.  out: the pair record's
+// RT_CUNITS candidate units.  Everything here is a conservative float32 filter; the absolute slack E covers the
+// rounding of P, of the cut planes / leaf records and of the differences (<= 6 Kp 2^-24 in all); the candidates
+// it lets through are re-expressed from float64.
+//
+// Whole-pair verdicts for spheres.  All sample origins lie in the cone around axis cB with tan(half angle) = kt;
+// with C = centre - P, ta = C.axis, dp = distance of C from the axis, c = |C|^2 - r^2 (float64, rounded):
+//   P outside (c > 1e-4 r^2): the sphere is seen from P under the half angle beta, tan(beta) = r / sqrt(c); every
+//     ray hits it iff  angle(C, axis) + alpha < beta  <=>  dp + kt ta < tan(beta) (ta - kt dp);  the light ray
+//     enters it at tau_out >= sqrt(c) from P and before |C| + r  ->  OCCLUDE for every ray when |C| + r < min |sample|;
+//   P on the sphere (|c| tiny): b = w.C is <= (ta + kt dp)/sqrt(1+kt^2) and >= (ta - kt dp)/sqrt(1+kt^2) over the
+//     cone;  b <= -bm for all rays: tau_out = -c / (|b| + sqrt(b^2 - c)), |tau_out| <= |c| / bm < 0.4e-6 -> AT_P;
+//     b >= bm for all rays: tau_out >= b >= bm > 1.1e-6 (the ray crosses P's own sphere) -> OCCLUDE.
+// The margins (1e-3 relative on the angles, bm = 1e-3 r) dwarf float32 and float64 rounding.
 template <int STRIDE>
-__device__ __forceinline__ uint32_t beam_collect(const DScene &S, const FastScene &F, BeamStack stk, d3 P, float cB0, float cB1,
-                                                 float cB2, float h0, float h1, float h2, float4 *out) {
+__device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene &F, BeamStack stk, d3 P, float cB0, float cB1,
+                                                float cB2, float h0, float h1, float h2, const LightQuad &Q, float4 *out) {
+    BeamOut R;
+    R.nu = 0; R.boxmask = 0; R.overflow = false; R.occ_all = false; R.atp_all = false;
     const float Pf0 = (float)P.x, Pf1 = (float)P.y, Pf2 = (float)P.z;
     const float Kp = fmaxf(fmaxf(fabsf(Pf0), fabsf(Pf1)), fmaxf(fabsf(Pf2), F.extent));
     const float E = Kp * RT_2M19 + 2e-6f;            // absolute slack on every plane position (and the 1e-6 offsets)
     const float L0 = cB0 - h0, L1 = cB1 - h1, L2 = cB2 - h2, U0 = cB0 + h0, U1 = cB1 + h1, U2 = cB2 + h2;
     const float iL0 = __builtin_amdgcn_rcpf(L0), iL1 = __builtin_amdgcn_rcpf(L1), iL2 = __builtin_amdgcn_rcpf(L2);
     const float iU0 = __builtin_amdgcn_rcpf(U0), iU1 = __builtin_amdgcn_rcpf(U1), iU2 = __builtin_amdgcn_rcpf(U2);
-    // the beam also lies inside the cone with apex P, axis cB and half-angle tan = |h| / |cB| (used for spheres)
+    // the beam also lies inside the cone with apex P and axis cB: a sample s = cB + e, |e| <= |h|, makes an angle
+    // with sin <= rho = |h| / |cB| with the axis, so tan <= rho / sqrt(1 - rho^2)
     const float cl2 = fmaf(cB0, cB0, fmaf(cB1, cB1, cB2 * cB2));
+    const float hh2 = fmaf(h0, h0, fmaf(h1, h1, h2 * h2));
     const float icl = __builtin_amdgcn_rsqf(cl2);
     const float ax0 = cB0 * icl, ax1 = cB1 * icl, ax2 = cB2 * icl;                    // |ax| = 1 +- 3e-7
-    const float kt = __builtin_amdgcn_sqrtf(fmaf(h0, h0, fmaf(h1, h1, h2 * h2))) * icl * 1.0001f;   // tan(half angle), rounded up
     const float ax_len = cl2 * icl;
+    const float rho2 = hh2 * icl * icl;
+    const bool cone_ok = rho2 < 0.25f;               // else: no cone culling, no whole-pair verdicts
+    const float kt = cone_ok ? __builtin_amdgcn_sqrtf(rho2) * __builtin_amdgcn_rsqf(1.0f - rho2) * 1.0001f : 1e30f;
+    const float smin = (ax_len - __builtin_amdgcn_sqrtf(hh2) * 1.000001f) * (1.0f - 1e-6f);   // <= |sample| for every sample
     float l0 = 0.0f, l1 = 1.0f;
     // root box relative to P
     clip_mul(l0, l1, -U0, -iU0, -((F.root_lo[0] - Pf0) - E)); clip_mul(l0, l1, L0, iL0, (F.root_hi[0] - Pf0) + E);
     clip_mul(l0, l1, -U1, -iU1, -((F.root_lo[1] - Pf1) - E)); clip_mul(l0, l1, L1, iL1, (F.root_hi[1] - Pf1) + E);
     clip_mul(l0, l1, -U2, -iU2, -((F.root_lo[2] - Pf2) - E)); clip_mul(l0, l1, L2, iL2, (F.root_hi[2] - Pf2) + E);
-    uint32_t n = 0, nu = 0, boxmask = 0;             // candidates, units used, which units start a box
+    uint32_t n = 0, nu = 0, boxmask = 0;             // candidates seen, units used, which units start a box
     uint32_t ids[RT_CMAX];                           // registers (static indices only): the pair's candidates so far
 #pragma unroll
     for (uint32_t j = 0; j < RT_CMAX; ++j) ids[j] = 0xffffffffu;
-    if (!(l0 <= l1)) return 0;
+    if (!(l0 <= l1)) return R;
     // One memory access per trip: a node step or a leaf entry.  The common trip (a leaf entry the beam's box
     // does not touch) is a 32-byte load, 13 additions and 6 compares.
     const uint32_t NONE = 0xffffffffu;
@@ -224,13 +261,14 @@ __device__ __forceinline__ uint32_t beam_collect(const DScene &S, const FastScen
             const bool touch = !(c0 - rr > bhi0) && !(d0 + rr < blo0) && !(c1 - rr > bhi1) && !(d1 + rr < blo1) &&
                                !(c2 - rr > bhi2) && !(d2 + rr < blo2);
             if (!touch) continue;
-            if (sph) {
+            float ta = 0.0f, dp2 = 0.0f, cn = 0.0f;
+            if (sph && cone_ok) {
                 // sphere against the cone: distance to the axis <= r (1 + tan) + axial position * tan (conservative).
                 // The distance comes from the cross product: its error is ~1e-7 |c|, inside the 2e-6 |c| below.
-                const float ta = fmaf(c0, ax0, fmaf(c1, ax1, c2 * ax2));
+                ta = fmaf(c0, ax0, fmaf(c1, ax1, c2 * ax2));
                 const float k0 = fmaf(c1, ax2, -(c2 * ax1)), k1 = fmaf(c2, ax0, -(c0 * ax2)), k2 = fmaf(c0, ax1, -(c1 * ax0));
-                const float dp2 = fmaf(k0, k0, fmaf(k1, k1, k2 * k2));
-                const float cn = (fabsf(c0) + fabsf(c1)) + fabsf(c2);                 // >= |c|
+                dp2 = fmaf(k0, k0, fmaf(k1, k1, k2 * k2));
+                cn = (fabsf(c0) + fabsf(c1)) + fabsf(c2);                             // >= |c|
                 const float lim = fmaf(lf.r, 1.0f + kt, fmaxf(ta, 0.0f) * kt) + E + 2e-6f * cn;
                 const bool in_cone = !(dp2 > lim * lim * 1.0001f) && !(ta < -(lf.r + E)) && !(ta > ax_len * (1.0f + kt) + lf.r + E);
                 if (!in_cone) continue;
@@ -239,19 +277,52 @@ __device__ __forceinline__ uint32_t beam_collect(const DScene &S, const FastScen
 #pragma unroll
             for (uint32_t j = 0; j < RT_CMAX; ++j) seen = seen || (j < n && ids[j] == prim);
             if (seen) continue;
-            if (nu + kind > RT_CUNITS) return RT_META_OVERFLOW;       // kind == units needed (sphere 1, box 2)
             const DPrim *pr = S.prims + prim;
+            bool store = true;
+            double dx = 0, dy = 0, dz = 0, cd = 0;
             if (sph) {
-                const double dx = pr->a[0] - P.x, dy = pr->a[1] - P.y, dz = pr->a[2] - P.z;
-                out[nu] = make_float4((float)dx, (float)dy, (float)dz, (float)(((dx * dx + dy * dy) + dz * dz) - pr->b[0]));
-                nu += 1;
-            } else {
-                out[nu] = make_float4(__double2float_rd(pr->a[0] - P.x), __double2float_rd(pr->a[1] - P.y),
-                                      __double2float_rd(pr->a[2] - P.z), __double2float_ru(pr->b[0] - P.x));
-                out[nu + 1] = make_float4(__double2float_ru(pr->b[1] - P.y), __double2float_ru(pr->b[2] - P.z), 0.0f, 0.0f);
-                boxmask |= 1u << nu;
-                nu += 2;
+                dx = pr->a[0] - P.x; dy = pr->a[1] - P.y; dz = pr->a[2] - P.z;
+                cd = ((dx * dx + dy * dy) + dz * dz) - pr->b[0];
+                if (cone_ok) {                       // whole-pair verdict (see above)
+                    // Every ray of the pair misses the sphere?  At the centre's axial depth ta the rays cross the
+                    // rectangle |x|, |y| <= aq t, t <= ta / (|cB| - ja); a line at angle phi to the axis stays
+                    // >= d cos(phi) away from a point at lateral distance d, and 1 / cos(phi) <= 1 + kt^2 / 2.
+                    if (ta > 0.0f) {
+                        const float tm = (ta + E) * __builtin_amdgcn_rcpf(ax_len - Q.ja) * 1.00001f * Q.aq + E;
+                        const float cu = fabsf(fmaf(c0, Q.u0, fmaf(c1, Q.u1, c2 * Q.u2))), cr = fabsf(fmaf(c0, Q.r0, fmaf(c1, Q.r1, c2 * Q.r2)));
+                        const float ex = fmaxf(cu - tm - 2e-6f * cn, 0.0f), ey = fmaxf(cr - tm - 2e-6f * cn, 0.0f);
+                        const float rl = fmaf(lf.r, fmaf(0.5f * kt, kt, 1.001f), E);
+                        if (fmaf(ex, ex, ey * ey) > rl * rl) continue;
+                    }
+                    const float cf = (float)cd, rr = lf.r, dp = __builtin_amdgcn_sqrtf(dp2);
+                    const float Cn = __builtin_amdgcn_sqrtf(fmaf(c0, c0, fmaf(c1, c1, c2 * c2)));
+                    const float bm = 1e-3f * rr;
+                    const bool ends_before = (Cn + rr) * 1.0001f + 1e-4f < smin;
+                    const float num = fmaf(kt, ta, dp), den = fmaf(-kt, dp, ta);       // dp + kt ta,  ta - kt dp
+                    if (cf > 1e-4f * rr * rr) {
+                        const float tb = rr * __builtin_amdgcn_rsqf(cf) * (1.0f - 1e-3f);
+                        if (ta > 0.0f && den > 0.0f && fmaf(num, 1.001f, 1e-6f * cn) < tb * den && ends_before) { R.occ_all = true; return R; }
+                    } else if (fabsf(cf) < 1e-3f * bm * bm && fabsf(cf) < 0.4e-6f * bm) {
+                        const float guard = bm * (1.0f + kt) * 1.001f + 1e-6f * cn;
+                        if (ta + kt * dp <= -guard) { R.atp_all = true; store = false; }
+                        else if (den >= guard && bm > 1e-5f && ends_before) { R.occ_all = true; return R; }
+                    }
+                }
             }
+            if (store) {
+                if (nu + kind > RT_CUNITS) { R.overflow = true; return R; }          // kind == units needed (sphere 1, box 2)
+                if (sph) {
+                    out[nu] = make_float4((float)dx, (float)dy, (float)dz, (float)cd);
+                    nu += 1;
+                } else {
+                    out[nu] = make_float4(__double2float_rd(pr->a[0] - P.x), __double2float_rd(pr->a[1] - P.y),
+                                          __double2float_rd(pr->a[2] - P.z), __double2float_ru(pr->b[0] - P.x));
+                    out[nu + 1] = make_float4(__double2float_ru(pr->b[1] - P.y), __double2float_ru(pr->b[2] - P.z), 0.0f, 0.0f);
+                    boxmask |= 1u << nu;
+                    nu += 2;
+                }
+            }
+            if (n >= RT_CMAX) { R.overflow = true; return R; }                       // the dedup list is full
 #pragma unroll
             for (uint32_t j = 0; j < RT_CMAX; ++j) if (j == n) ids[j] = prim;
             ++n;
@@ -294,5 +365,6 @@ __device__ __forceinline__ uint32_t beam_collect(const DScene &S, const FastScen
         else if (goR) { node = nd.b >> 2; l0 = b0; l1 = b1; }
         else node = NONE;
     }
-    return nu | (boxmask << 8);
+    R.nu = nu; R.boxmask = boxmask;
+    return R;
 }
