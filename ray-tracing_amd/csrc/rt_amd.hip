@@ -45,6 +45,8 @@ struct FrameCtl {
     unsigned long long reflect_rays, transmit_rays, primary_rays;
     uint32_t n_listed[RT_MAX_LEVELS + 2];   // diagnostics: pairs that needed the per-ray filter / rays that needed
     uint32_t n_queued[RT_MAX_LEVELS + 2];   // the float64 queue, per level (copied by k_shade)
+    uint32_t dbg_max_trips, dbg_pad;        // RT_FLAG 0x1000: longest / total beam traversal of the frame
+    unsigned long long dbg_sum_trips;
 };
 
 struct RayQ {            // SoA ray queue in HBM
@@ -330,10 +332,11 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_setup(DScene S, LevelParams
 //   listed: header + candidate units go to rec[pair], the pair gets a slot in bb.list (wave-aggregated append);
 //   numerically delicate basis / too many candidates: listed with the overflow mark, all its rays go to the
 //     float64 queue.
-__global__ void __launch_bounds__(RT_BLOCK) k_beam_setup(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb, BeamBuf bb,
+__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) k_beam_setup(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb, BeamBuf bb,
                                                          FrameCtl *ctl) {
     extern __shared__ uint2 lds_stack[];
     __shared__ uint32_t lbuf_all[(RT_BLOCK / 64) * 128];
+    __shared__ uint32_t tl_all[RT_TOUCH * RT_BLOCK];     // [entry][lane]: touched leaf entries of the lane's traversal
     if (ctl->overflow) return;
     const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
     const uint32_t nsl = (uint32_t)S.n_shadow_lights;
@@ -343,14 +346,20 @@ __global__ void __launch_bounds__(RT_BLOCK) k_beam_setup(DScene S, FastScene F, 
     // atomic on the list counter per 64 pairs; see k_shadow_beam)
     uint32_t *lbuf = lbuf_all + (threadIdx.x >> 6) * 128;
     uint32_t ln = 0u;
-    ChunkWalk walk(total);
+    // A wave takes 64 CONSECUTIVE HITS and ONE light: neighbouring hits (neighbouring pixels at level 0) send
+    // nearly the same beam through the tree, the lanes of a wave stay on one path.
+    const uint32_t hit_blocks = (n_hits + 63u) >> 6;
+    ChunkWalk walk((uint64_t)hit_blocks * nsl * 64u);
     uint64_t first;
+    (void)total;
     while (walk.next(first)) {
-        const uint32_t seg = (uint32_t)first + threadIdx.x;
-        const bool valid = seg < total;
+        const uint32_t wg = (uint32_t)(first >> 6) + (threadIdx.x >> 6);     // (hit block, light)
+        const uint32_t hblk = wg / nsl, ml = wg - hblk * nsl;
+        const uint32_t h = (hblk << 6) + (uint32_t)lane;
+        const bool valid = hblk < hit_blocks && h < n_hits;
+        const uint32_t seg = h * nsl + ml;
         bool listed = false;
         if (valid) {
-            const uint32_t h = seg / nsl, ml = seg - h * nsl;
             const uint32_t r = hb.list[h];
             const int m = S.shadow_lights[ml];
             const d3 P = mk3(hb.px[r], hb.py[r], hb.pz[r]);
@@ -399,9 +408,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_beam_setup(DScene S, FastScene F, 
             h0 = fmaf(RT_2M18, fabsf(cB0) + h0, h0) + 1e-5f;
             h1 = fmaf(RT_2M18, fabsf(cB1) + h1, h1) + 1e-5f;
             h2 = fmaf(RT_2M18, fabsf(cB2) + h2, h2) + 1e-5f;
-            BeamStack bs;
-            bs.a = lds_stack + threadIdx.x;
-            bs.b = (float *)(lds_stack + (size_t)F.depth * RT_BLOCK) + threadIdx.x;
+            uint2 *bs = lds_stack + threadIdx.x;
             uint32_t pcls = 0, n_eval = 0, n_atp = 0;      // whole-pair verdicts of the planes
 #pragma unroll
             for (int k = 0; k < RT_PMAX; ++k)
@@ -413,7 +420,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_beam_setup(DScene S, FastScene F, 
                     n_atp += c == RT_PLANE_ATP;
                 }
             BeamOut bo;
-            bo.nu = 0; bo.boxmask = 0; bo.overflow = true; bo.occ_all = false; bo.atp_all = false;
+            bo.nu = 0; bo.boxmask = 0; bo.overflow = true; bo.occ_all = false; bo.atp_all = false; bo.trips = 0;
             if (!delicate) {
                 if (lp.flags & 0x100) bo.overflow = false;   // timing experiment only
                 else {
@@ -422,9 +429,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_beam_setup(DScene S, FastScene F, 
                     const float ur = fabsf(u0 * r0) + fabsf(u1 * r1) + fabsf(u2 * r2);
                     Q.aq = (0.5f * sm1 * g + g * (1.0f + ur)) * 1.0001f + 1e-5f;
                     Q.ja = (g * ((fabsf(u0) + fabsf(r0)) * fabsf(D0) + (fabsf(u1) + fabsf(r1)) * fabsf(D1) + (fabsf(u2) + fabsf(r2)) * fabsf(D2))) * 1.0001f + 1e-5f;
-                    bo = beam_collect<RT_BLOCK>(S, F, bs, P, cB0, cB1, cB2, h0, h1, h2, Q, rec + 4);
+                    bo = beam_collect<RT_BLOCK>(S, F, bs, tl_all + threadIdx.x, P, cB0, cB1, cB2, h0, h1, h2, Q, rec + 4, lp.flags);
                 }
             }
+            if (lp.flags & 0x1000) { atomicMax(&ctl->dbg_max_trips, bo.trips); atomicAdd(&ctl->dbg_sum_trips, (unsigned long long)bo.trips); }
             // every |sample - P| inside the per-ray filter's range (k_shadow_beam: 1e-4 < nv < 1e7)
             const float sc = sqrtf(fmaf(cB0, cB0, fmaf(cB1, cB1, cB2 * cB2))), sh = sqrtf(fmaf(h0, h0, fmaf(h1, h1, h2 * h2)));
             const bool range_ok = sc - sh > 1e-3f && sc + sh < 1e6f;
@@ -1245,7 +1253,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
             memcpy(&kn[i].a, &cf, 4);
             kn[i].b = ((uint32_t)R << 2) | (uint32_t)axis;
         }
-        if (max_depth > 40) ok = false;   // per-lane stacks (12 B per level in the beam kernel) must fit the 160 KB LDS   // per-lane stacks must fit the default 64 KB dynamic-LDS limit
+        if (max_depth > 64) ok = false;   // per-lane stacks (8 B per level and lane) must fit the 160 KB LDS
         for (int e = 0; e < s->n_leaf_refs; ++e) {
             const int p = s->leaf_prim[e];
             LeafF &f = lf[e];
@@ -1283,7 +1291,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
             HIP_C(hipFuncSetAttribute((const void *)&k_intersect<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow_queue, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup, hipFuncAttributeMaxDynamicSharedMemorySize, big - 4096));   // 2 KB of static LDS (list buffer)
+            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));   // 14 KB of static LDS (list buffer, touched entries)
             HIP_C(hipFuncSetAttribute((const void *)&k_intersect_only<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         }
         if (getenv("RT_AMD_DEBUG")) fprintf(stderr, "[rt_amd] kd view: ok=%d depth=%d lds=%zu B\n", ctx->F.ok, max_depth, ctx->lds_bytes);
@@ -1306,7 +1314,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
         ctx->g_intersect_x = grid_for((const void *)&k_intersect<false>, 0);
         ctx->g_shadow = grid_for((const void *)&k_shadow<true>, lds);
         ctx->g_shadow_x = grid_for((const void *)&k_shadow<false>, 0);
-        ctx->g_beam_setup = grid_for((const void *)&k_beam_setup, lds * 3 / 2);
+        ctx->g_beam_setup = grid_for((const void *)&k_beam_setup, lds);
         ctx->g_beam = grid_for((const void *)&k_shadow_beam, 0);
         ctx->g_queue = grid_for((const void *)&k_shadow_queue, lds);
         ctx->g_shade = grid_for((const void *)&k_shade, 0);
@@ -1545,7 +1553,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         if (ctx->S.n_shadow_lights > 0) {
             if (beam) {
                 HIP_TRY(ctx, hipMemsetAsync(ctx->beam.queue_n, 0, 2 * sizeof(uint32_t), st));
-                hipLaunchKernelGGL(k_beam_setup, dim3(ctx->g_beam_setup), block, ctx->lds_bytes * 3 / 2, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->beam, ctx->ctl);
+                hipLaunchKernelGGL(k_beam_setup, dim3(ctx->g_beam_setup), block, ctx->lds_bytes, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->beam, ctx->ctl);
                 hipLaunchKernelGGL(k_shadow_beam, dim3(ctx->g_beam), block, 0, st, ctx->S, lp, ctx->hb, ctx->beam, ctx->ctl);
                 hipLaunchKernelGGL(k_shadow_queue, dim3(ctx->g_queue), block, ctx->lds_bytes, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->seg, ctx->beam, ctx->ctl);
             } else {
@@ -1665,6 +1673,7 @@ extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
         for (int l = 0; l <= ctx->last_rec && l < RT_MAX_LEVELS; ++l)
             fprintf(stderr, "[rt_amd] level %d: %llu pairs, %u listed, %u rays queued\n", l,
                     (unsigned long long)c.n_hits[l] * (unsigned long long)ctx->S.n_shadow_lights, c.n_listed[l], c.n_queued[l]);
+        fprintf(stderr, "[rt_amd] beam traversal trips (flag 0x1000): max %u, total %llu\n", c.dbg_max_trips, c.dbg_sum_trips);
         // candidate units of the listed pairs of the LAST level (render with rec_max = 0 to see level 0)
         uint32_t qn[4] = {0, 0, 0, 0};
         (void)hipMemcpy(qn, ctx->beam.queue_n, sizeof(qn), hipMemcpyDeviceToHost);

@@ -19,10 +19,12 @@
 // queue and decided by the float64 path of rt_fast.hpp (k_shadow_queue).  So the outcome is that
 // of the float64 reference-order evaluation, at float32 VALU cost for ~99.9 % of the rays.
 #pragma once
+#include <hip/hip_fp16.h>
 #include "rt_fast.hpp"
 
 #define RT_CUNITS 8          // 16-byte candidate units kept per (hit, light) pair: a sphere takes 1, a box 2
 #define RT_CMAX RT_CUNITS
+#define RT_TOUCH 8          // leaf entries a pair's traversal may park before its rays go to the float64 queue
 #define RT_PMAX 3            // planes handled by the filtered path
 #define RT_PAIR_UNITS (4 + RT_CUNITS)   // one pair record = 12 float4 = 192 B, contiguous
 
@@ -174,10 +176,19 @@ __device__ __forceinline__ void clip_mul(float &l0, float &l1, float coef, float
     l1 = (coef == 0.0f && rhs < 0.0f) ? -1.0f : l1;  // 0 <= rhs fails: empty
 }
 
-struct BeamStack {           // LDS columns, one entry per tree level
-    uint2 *a;                // (node, lambda0 bits)
-    float *b;                // lambda1
-};
+// Stack entry of the beam traversal: (node, lambda interval as two float16, rounded outward by up to 1.5 ulp).
+// 8 bytes per level and lane, like the stacks of rt_fast.hpp; lambda is in [0, 1], 2^-11 relative is ~0.01
+// length units at the far end of a beam.
+__device__ __forceinline__ uint32_t pack_lambda(float l0, float l1) {
+    uint32_t a = __half_as_ushort(__float2half_rn(l0)), b = __half_as_ushort(__float2half_rn(l1));
+    a = a ? a - 1u : 0u;     // l0 >= 0: one float16 ulp down
+    b = b + 1u;              // l1 <= 1: one ulp up, cannot overflow
+    return a | (b << 16);
+}
+__device__ __forceinline__ void unpack_lambda(uint32_t p, float &l0, float &l1) {
+    l0 = __half2float(__ushort_as_half((unsigned short)(p & 0xffffu)));
+    l1 = __half2float(__ushort_as_half((unsigned short)(p >> 16)));
+}
 
 __device__ __forceinline__ float sel3(uint32_t ax, float v0, float v1, float v2) { return ax == 0 ? v0 : (ax == 1 ? v1 : v2); }
 
@@ -194,6 +205,7 @@ struct BeamOut {
     bool overflow;           // the units do not suffice: every ray of the pair goes to the float64 queue
     bool occ_all;            // one sphere occludes EVERY ray of the pair (traversal stopped there)
     bool atp_all;            // P lies on a sphere that every ray of the pair leaves through P (not stored in out[])
+    uint32_t trips;          // diagnostics: node steps + leaf entries looked at
 };
 
 // c* / h*: centre and half size of the box of all sample origins, relative to P.  out: the pair record's
@@ -211,10 +223,10 @@ struct BeamOut {
 //     b >= bm for all rays: tau_out >= b >= bm > 1.1e-6 (the ray crosses P's own sphere) -> OCCLUDE.
 // The margins (1e-3 relative on the angles, bm = 1e-3 r) dwarf float32 and float64 rounding.
 template <int STRIDE>
-__device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene &F, BeamStack stk, d3 P, float cB0, float cB1,
-                                                float cB2, float h0, float h1, float h2, const LightQuad &Q, float4 *out) {
+__device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene &F, uint2 *stk, uint32_t *tl, d3 P, float cB0, float cB1,
+                                                float cB2, float h0, float h1, float h2, const LightQuad &Q, float4 *out, int dbg) {
     BeamOut R;
-    R.nu = 0; R.boxmask = 0; R.overflow = false; R.occ_all = false; R.atp_all = false;
+    R.nu = 0; R.boxmask = 0; R.overflow = false; R.occ_all = false; R.atp_all = false; R.trips = 0;
     const float Pf0 = (float)P.x, Pf1 = (float)P.y, Pf2 = (float)P.z;
     const float Kp = fmaxf(fmaxf(fabsf(Pf0), fabsf(Pf1)), fmaxf(fabsf(Pf2), F.extent));
     const float E = Kp * RT_2M19 + 2e-6f;            // absolute slack on every plane position (and the 1e-6 offsets)
@@ -237,133 +249,141 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
     clip_mul(l0, l1, -U0, -iU0, -((F.root_lo[0] - Pf0) - E)); clip_mul(l0, l1, L0, iL0, (F.root_hi[0] - Pf0) + E);
     clip_mul(l0, l1, -U1, -iU1, -((F.root_lo[1] - Pf1) - E)); clip_mul(l0, l1, L1, iL1, (F.root_hi[1] - Pf1) + E);
     clip_mul(l0, l1, -U2, -iU2, -((F.root_lo[2] - Pf2) - E)); clip_mul(l0, l1, L2, iL2, (F.root_hi[2] - Pf2) + E);
+    if (!(l0 <= l1)) return R;
+
+    // ---- phase 1: traversal.  The loops carry only the traversal state; a leaf entry that passes the float32
+    // tests is parked in the lane's LDS list tl[] (RT_TOUCH entries) and looked at after the traversal.
+    const uint32_t NONE = 0xffffffffu;
+    uint32_t node = 0, nt = 0, ntu = 0;              // touched entries, and the candidate units they would need
+    int sp = 0;
+    for (;;) {
+        // descend to a leaf (left first; the right child waits on the stack when the beam reaches both)
+        KNode nd = F.knodes[node];
+        while ((nd.b & 3u) != 3u) {
+            const uint32_t ax = nd.b & 3u;
+            ++R.trips;
+            const float cut = __uint_as_float(nd.a) - sel3(ax, Pf0, Pf1, Pf2);
+            const float La = sel3(ax, L0, L1, L2), Ua = sel3(ax, U0, U1, U2), iLa = sel3(ax, iL0, iL1, iL2), iUa = sel3(ax, iU0, iU1, iU2);
+            float a0 = l0, a1 = l1, b0 = l0, b1 = l1;
+            clip_mul(a0, a1, La, iLa, cut + E);          // left child: some beam point with x <= cut
+            clip_mul(b0, b1, -Ua, -iUa, -(cut - E));     // right child: some beam point with x >= cut
+            const bool goL = a0 <= a1, goR = b0 <= b1;
+            if (goL && goR) {
+                stk[sp * STRIDE] = make_uint2(nd.b >> 2, pack_lambda(b0, b1));
+                ++sp;
+            }
+            if (goL) { node = node + 1; l0 = a0; l1 = a1; }
+            else if (goR) { node = nd.b >> 2; l0 = b0; l1 = b1; }
+            else { node = NONE; break; }
+            nd = F.knodes[node];
+        }
+        if (node != NONE) {
+            // leaf: beam bounding box over this leaf's lambda range (slightly widened)
+            const float m0 = fmaxf(l0 - 1e-6f, 0.0f), m1 = fminf(l1 + 1e-6f, 1.0f);
+            const float blo0 = fminf(m0 * L0, m1 * L0) - E, bhi0 = fmaxf(m0 * U0, m1 * U0) + E;
+            const float blo1 = fminf(m0 * L1, m1 * L1) - E, bhi1 = fmaxf(m0 * U1, m1 * U1) + E;
+            const float blo2 = fminf(m0 * L2, m1 * L2) - E, bhi2 = fmaxf(m0 * U2, m1 * U2) + E;
+            const uint32_t e_end = nd.a + (nd.b >> 2);
+            for (uint32_t e = nd.a; e < e_end && nt <= RT_TOUCH && ntu <= RT_CUNITS + 4u; ++e) {   // (leaves at the depth limit hold hundreds of entries)
+                const LeafF lf = F.leaves[e];
+                ++R.trips;
+                const bool sph = (lf.pk & 3u) == 1u;     // sphere {centre, r, (low parts)}; box {lo, -, hi}
+                const float rr = sph ? lf.r : 0.0f;
+                const float c0 = lf.x - Pf0, c1 = lf.y - Pf1, c2 = lf.z - Pf2;
+                const float d0 = sph ? c0 : lf.lx - Pf0, d1 = sph ? c1 : lf.ly - Pf1, d2 = sph ? c2 : lf.lz - Pf2;
+                const bool touch = !(c0 - rr > bhi0) && !(d0 + rr < blo0) && !(c1 - rr > bhi1) && !(d1 + rr < blo1) &&
+                                   !(c2 - rr > bhi2) && !(d2 + rr < blo2);
+                if (touch) {
+                    if (nt < RT_TOUCH) tl[nt * STRIDE] = e;
+                    ++nt;
+                    ntu += sph ? 1u : 2u;
+                }
+            }
+        }
+        if (sp == 0 || nt > RT_TOUCH || ntu > RT_CUNITS + 4u) break;   // the pair overflows whatever else the beam meets (boxes crowding around P)
+        --sp;
+        const uint2 t = stk[sp * STRIDE];
+        node = t.x;
+        unpack_lambda(t.y, l0, l1);
+    }
+    if (nt > RT_TOUCH || ntu > RT_CUNITS + 4u || (dbg & 0x2000)) { R.overflow = true; return R; }
+
+    // ---- phase 2: the touched entries.  Cone test, duplicates (a primitive is listed in several leaves),
+    // whole-pair verdicts, float64 re-expression.
     uint32_t n = 0, nu = 0, boxmask = 0;             // candidates seen, units used, which units start a box
     uint32_t ids[RT_CMAX];                           // registers (static indices only): the pair's candidates so far
 #pragma unroll
     for (uint32_t j = 0; j < RT_CMAX; ++j) ids[j] = 0xffffffffu;
-    if (!(l0 <= l1)) return R;
-    // One memory access per trip: a node step or a leaf entry.  The common trip (a leaf entry the beam's box
-    // does not touch) is a 32-byte load, 13 additions and 6 compares.
-    const uint32_t NONE = 0xffffffffu;
-    uint32_t node = 0, e = 0, e_end = 0;
-    int sp = 0;
-    float blo0 = 0, blo1 = 0, blo2 = 0, bhi0 = 0, bhi1 = 0, bhi2 = 0;
-    for (;;) {
-        if (e < e_end) {
-            // ---- one leaf entry ----
-            const LeafF lf = F.leaves[e];
-            ++e;
-            const uint32_t kind = lf.pk & 3u, prim = lf.pk >> 2;
-            const bool sph = kind == 1u;             // sphere {centre, r, (low parts)}; box {lo, -, hi}
-            const float rr = sph ? lf.r : 0.0f;
-            const float c0 = lf.x - Pf0, c1 = lf.y - Pf1, c2 = lf.z - Pf2;
-            const float d0 = sph ? c0 : lf.lx - Pf0, d1 = sph ? c1 : lf.ly - Pf1, d2 = sph ? c2 : lf.lz - Pf2;
-            const bool touch = !(c0 - rr > bhi0) && !(d0 + rr < blo0) && !(c1 - rr > bhi1) && !(d1 + rr < blo1) &&
-                               !(c2 - rr > bhi2) && !(d2 + rr < blo2);
-            if (!touch) continue;
-            float ta = 0.0f, dp2 = 0.0f, cn = 0.0f;
-            if (sph && cone_ok) {
-                // sphere against the cone: distance to the axis <= r (1 + tan) + axial position * tan (conservative).
-                // The distance comes from the cross product: its error is ~1e-7 |c|, inside the 2e-6 |c| below.
-                ta = fmaf(c0, ax0, fmaf(c1, ax1, c2 * ax2));
-                const float k0 = fmaf(c1, ax2, -(c2 * ax1)), k1 = fmaf(c2, ax0, -(c0 * ax2)), k2 = fmaf(c0, ax1, -(c1 * ax0));
-                dp2 = fmaf(k0, k0, fmaf(k1, k1, k2 * k2));
-                cn = (fabsf(c0) + fabsf(c1)) + fabsf(c2);                             // >= |c|
-                const float lim = fmaf(lf.r, 1.0f + kt, fmaxf(ta, 0.0f) * kt) + E + 2e-6f * cn;
-                const bool in_cone = !(dp2 > lim * lim * 1.0001f) && !(ta < -(lf.r + E)) && !(ta > ax_len * (1.0f + kt) + lf.r + E);
-                if (!in_cone) continue;
-            }
-            bool seen = false;                       // the same primitive is listed in several leaves
+    for (uint32_t k = 0; k < nt; ++k) {
+        const LeafF lf = F.leaves[tl[k * STRIDE]];
+        const uint32_t kind = lf.pk & 3u, prim = lf.pk >> 2;
+        const bool sph = kind == 1u;
+        const float c0 = lf.x - Pf0, c1 = lf.y - Pf1, c2 = lf.z - Pf2;
+        float ta = 0.0f, dp2 = 0.0f, cn = 0.0f;
+        if (sph && cone_ok) {
+            // sphere against the cone: distance to the axis <= r (1 + tan) + axial position * tan (conservative).
+            // The distance comes from the cross product: its error is ~1e-7 |c|, inside the 2e-6 |c| below.
+            ta = fmaf(c0, ax0, fmaf(c1, ax1, c2 * ax2));
+            const float k0 = fmaf(c1, ax2, -(c2 * ax1)), k1 = fmaf(c2, ax0, -(c0 * ax2)), k2 = fmaf(c0, ax1, -(c1 * ax0));
+            dp2 = fmaf(k0, k0, fmaf(k1, k1, k2 * k2));
+            cn = (fabsf(c0) + fabsf(c1)) + fabsf(c2);                             // >= |c|
+            const float lim = fmaf(lf.r, 1.0f + kt, fmaxf(ta, 0.0f) * kt) + E + 2e-6f * cn;
+            const bool in_cone = !(dp2 > lim * lim * 1.0001f) && !(ta < -(lf.r + E)) && !(ta > ax_len * (1.0f + kt) + lf.r + E);
+            if (!in_cone) continue;
+        }
+        bool seen = false;
 #pragma unroll
-            for (uint32_t j = 0; j < RT_CMAX; ++j) seen = seen || (j < n && ids[j] == prim);
-            if (seen) continue;
-            const DPrim *pr = S.prims + prim;
-            bool store = true;
-            double dx = 0, dy = 0, dz = 0, cd = 0;
+        for (uint32_t j = 0; j < RT_CMAX; ++j) seen = seen || (j < n && ids[j] == prim);
+        if (seen) continue;
+        const DPrim *pr = S.prims + prim;
+        bool store = true;
+        double dx = 0, dy = 0, dz = 0, cd = 0;
+        if (sph) {
+            dx = pr->a[0] - P.x; dy = pr->a[1] - P.y; dz = pr->a[2] - P.z;
+            cd = ((dx * dx + dy * dy) + dz * dz) - pr->b[0];
+            if (cone_ok) {                       // whole-pair verdict (see above)
+                // Every ray of the pair misses the sphere?  At the centre's axial depth ta the rays cross the
+                // rectangle |x|, |y| <= aq t, t <= ta / (|cB| - ja); a line at angle phi to the axis stays
+                // >= d cos(phi) away from a point at lateral distance d, and 1 / cos(phi) <= 1 + kt^2 / 2.
+                if (ta > 0.0f) {
+                    const float tm = (ta + E) * __builtin_amdgcn_rcpf(ax_len - Q.ja) * 1.00001f * Q.aq + E;
+                    const float cu = fabsf(fmaf(c0, Q.u0, fmaf(c1, Q.u1, c2 * Q.u2))), cr = fabsf(fmaf(c0, Q.r0, fmaf(c1, Q.r1, c2 * Q.r2)));
+                    const float ex = fmaxf(cu - tm - 2e-6f * cn, 0.0f), ey = fmaxf(cr - tm - 2e-6f * cn, 0.0f);
+                    const float rl = fmaf(lf.r, fmaf(0.5f * kt, kt, 1.001f), E);
+                    if (fmaf(ex, ex, ey * ey) > rl * rl) continue;
+                }
+                const float cf = (float)cd, rr = lf.r, dp = __builtin_amdgcn_sqrtf(dp2);
+                const float Cn = __builtin_amdgcn_sqrtf(fmaf(c0, c0, fmaf(c1, c1, c2 * c2)));
+                const float bm = 1e-3f * rr;
+                const bool ends_before = (Cn + rr) * 1.0001f + 1e-4f < smin;
+                const float num = fmaf(kt, ta, dp), den = fmaf(-kt, dp, ta);       // dp + kt ta,  ta - kt dp
+                if (cf > 1e-4f * rr * rr) {
+                    const float tb = rr * __builtin_amdgcn_rsqf(cf) * (1.0f - 1e-3f);
+                    if (ta > 0.0f && den > 0.0f && fmaf(num, 1.001f, 1e-6f * cn) < tb * den && ends_before) { R.occ_all = true; return R; }
+                } else if (fabsf(cf) < 1e-3f * bm * bm && fabsf(cf) < 0.4e-6f * bm) {
+                    const float guard = bm * (1.0f + kt) * 1.001f + 1e-6f * cn;
+                    if (ta + kt * dp <= -guard) { R.atp_all = true; store = false; }
+                    else if (den >= guard && bm > 1e-5f && ends_before) { R.occ_all = true; return R; }
+                }
+            }
+        }
+        if (store) {
+            if (nu + kind > RT_CUNITS) { R.overflow = true; return R; }          // kind == units needed (sphere 1, box 2)
             if (sph) {
-                dx = pr->a[0] - P.x; dy = pr->a[1] - P.y; dz = pr->a[2] - P.z;
-                cd = ((dx * dx + dy * dy) + dz * dz) - pr->b[0];
-                if (cone_ok) {                       // whole-pair verdict (see above)
-                    // Every ray of the pair misses the sphere?  At the centre's axial depth ta the rays cross the
-                    // rectangle |x|, |y| <= aq t, t <= ta / (|cB| - ja); a line at angle phi to the axis stays
-                    // >= d cos(phi) away from a point at lateral distance d, and 1 / cos(phi) <= 1 + kt^2 / 2.
-                    if (ta > 0.0f) {
-                        const float tm = (ta + E) * __builtin_amdgcn_rcpf(ax_len - Q.ja) * 1.00001f * Q.aq + E;
-                        const float cu = fabsf(fmaf(c0, Q.u0, fmaf(c1, Q.u1, c2 * Q.u2))), cr = fabsf(fmaf(c0, Q.r0, fmaf(c1, Q.r1, c2 * Q.r2)));
-                        const float ex = fmaxf(cu - tm - 2e-6f * cn, 0.0f), ey = fmaxf(cr - tm - 2e-6f * cn, 0.0f);
-                        const float rl = fmaf(lf.r, fmaf(0.5f * kt, kt, 1.001f), E);
-                        if (fmaf(ex, ex, ey * ey) > rl * rl) continue;
-                    }
-                    const float cf = (float)cd, rr = lf.r, dp = __builtin_amdgcn_sqrtf(dp2);
-                    const float Cn = __builtin_amdgcn_sqrtf(fmaf(c0, c0, fmaf(c1, c1, c2 * c2)));
-                    const float bm = 1e-3f * rr;
-                    const bool ends_before = (Cn + rr) * 1.0001f + 1e-4f < smin;
-                    const float num = fmaf(kt, ta, dp), den = fmaf(-kt, dp, ta);       // dp + kt ta,  ta - kt dp
-                    if (cf > 1e-4f * rr * rr) {
-                        const float tb = rr * __builtin_amdgcn_rsqf(cf) * (1.0f - 1e-3f);
-                        if (ta > 0.0f && den > 0.0f && fmaf(num, 1.001f, 1e-6f * cn) < tb * den && ends_before) { R.occ_all = true; return R; }
-                    } else if (fabsf(cf) < 1e-3f * bm * bm && fabsf(cf) < 0.4e-6f * bm) {
-                        const float guard = bm * (1.0f + kt) * 1.001f + 1e-6f * cn;
-                        if (ta + kt * dp <= -guard) { R.atp_all = true; store = false; }
-                        else if (den >= guard && bm > 1e-5f && ends_before) { R.occ_all = true; return R; }
-                    }
-                }
+                out[nu] = make_float4((float)dx, (float)dy, (float)dz, (float)cd);
+                nu += 1;
+            } else {
+                out[nu] = make_float4(__double2float_rd(pr->a[0] - P.x), __double2float_rd(pr->a[1] - P.y),
+                                      __double2float_rd(pr->a[2] - P.z), __double2float_ru(pr->b[0] - P.x));
+                out[nu + 1] = make_float4(__double2float_ru(pr->b[1] - P.y), __double2float_ru(pr->b[2] - P.z), 0.0f, 0.0f);
+                boxmask |= 1u << nu;
+                nu += 2;
             }
-            if (store) {
-                if (nu + kind > RT_CUNITS) { R.overflow = true; return R; }          // kind == units needed (sphere 1, box 2)
-                if (sph) {
-                    out[nu] = make_float4((float)dx, (float)dy, (float)dz, (float)cd);
-                    nu += 1;
-                } else {
-                    out[nu] = make_float4(__double2float_rd(pr->a[0] - P.x), __double2float_rd(pr->a[1] - P.y),
-                                          __double2float_rd(pr->a[2] - P.z), __double2float_ru(pr->b[0] - P.x));
-                    out[nu + 1] = make_float4(__double2float_ru(pr->b[1] - P.y), __double2float_ru(pr->b[2] - P.z), 0.0f, 0.0f);
-                    boxmask |= 1u << nu;
-                    nu += 2;
-                }
-            }
-            if (n >= RT_CMAX) { R.overflow = true; return R; }                       // the dedup list is full
+        }
+        if (n >= RT_CMAX) { R.overflow = true; return R; }                       // the dedup list is full
 #pragma unroll
-            for (uint32_t j = 0; j < RT_CMAX; ++j) if (j == n) ids[j] = prim;
-            ++n;
-            continue;
-        }
-        if (node == NONE) {
-            if (sp == 0) break;
-            --sp;
-            const uint2 t = stk.a[sp * STRIDE];
-            node = t.x;
-            l0 = __uint_as_float(t.y);
-            l1 = stk.b[sp * STRIDE];
-        }
-        // ---- one node ----
-        const KNode nd = F.knodes[node];
-        if ((nd.b & 3u) == 3u) {
-            // leaf: beam bounding box over this leaf's lambda range (slightly widened)
-            const float m0 = fmaxf(l0 - 1e-6f, 0.0f), m1 = fminf(l1 + 1e-6f, 1.0f);
-            blo0 = fminf(m0 * L0, m1 * L0) - E; bhi0 = fmaxf(m0 * U0, m1 * U0) + E;
-            blo1 = fminf(m0 * L1, m1 * L1) - E; bhi1 = fmaxf(m0 * U1, m1 * U1) + E;
-            blo2 = fminf(m0 * L2, m1 * L2) - E; bhi2 = fmaxf(m0 * U2, m1 * U2) + E;
-            e = nd.a;
-            e_end = nd.a + (nd.b >> 2);
-            node = NONE;
-            continue;
-        }
-        const uint32_t ax = nd.b & 3u;
-        const float cut = __uint_as_float(nd.a) - sel3(ax, Pf0, Pf1, Pf2);
-        const float La = sel3(ax, L0, L1, L2), Ua = sel3(ax, U0, U1, U2), iLa = sel3(ax, iL0, iL1, iL2), iUa = sel3(ax, iU0, iU1, iU2);
-        float a0 = l0, a1 = l1, b0 = l0, b1 = l1;
-        clip_mul(a0, a1, La, iLa, cut + E);          // left child: some beam point with x <= cut
-        clip_mul(b0, b1, -Ua, -iUa, -(cut - E));     // right child: some beam point with x >= cut
-        const bool goL = a0 <= a1, goR = b0 <= b1;
-        if (goL && goR) {
-            stk.a[sp * STRIDE] = make_uint2(nd.b >> 2, __float_as_uint(b0));
-            stk.b[sp * STRIDE] = b1;
-            ++sp;
-        }
-        if (goL) { node = node + 1; l0 = a0; l1 = a1; }
-        else if (goR) { node = nd.b >> 2; l0 = b0; l1 = b1; }
-        else node = NONE;
+        for (uint32_t j = 0; j < RT_CMAX; ++j) if (j == n) ids[j] = prim;
+        ++n;
     }
     R.nu = nu; R.boxmask = boxmask;
     return R;
