@@ -46,6 +46,7 @@ struct FrameCtl {
     uint32_t n_listed[RT_MAX_LEVELS + 2];   // diagnostics: pairs that needed the per-ray filter / rays that needed
     uint32_t n_queued[RT_MAX_LEVELS + 2];   // the float64 queue, per level (copied by k_shade)
     uint32_t dbg_max_trips, dbg_pad;        // RT_FLAG 0x1000: longest / total beam traversal of the frame
+    uint32_t dbg_why[4];                    // pairs sent to the queue: delicate basis, touched list, units, dedup list
     unsigned long long dbg_sum_trips;
 };
 
@@ -420,7 +421,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                     n_atp += c == RT_PLANE_ATP;
                 }
             BeamOut bo;
-            bo.nu = 0; bo.boxmask = 0; bo.overflow = true; bo.occ_all = false; bo.atp_all = false; bo.trips = 0;
+            bo.nu = 0; bo.boxmask = 0; bo.overflow = true; bo.occ_all = false; bo.atp_all = false; bo.trips = 0; bo.why = 0;
             if (!delicate) {
                 if (lp.flags & 0x100) bo.overflow = false;   // timing experiment only
                 else {
@@ -432,7 +433,10 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                     bo = beam_collect<RT_BLOCK>(S, F, bs, tl_all + threadIdx.x, P, cB0, cB1, cB2, h0, h1, h2, Q, rec + 4, lp.flags);
                 }
             }
-            if (lp.flags & 0x1000) { atomicMax(&ctl->dbg_max_trips, bo.trips); atomicAdd(&ctl->dbg_sum_trips, (unsigned long long)bo.trips); }
+            if (lp.flags & 0x1000) {
+                atomicMax(&ctl->dbg_max_trips, bo.trips); atomicAdd(&ctl->dbg_sum_trips, (unsigned long long)bo.trips);
+                if (bo.overflow) atomicAdd(&ctl->dbg_why[delicate ? 0 : bo.why], 1u);
+            }
             // every |sample - P| inside the per-ray filter's range (k_shadow_beam: 1e-4 < nv < 1e7)
             const float sc = sqrtf(fmaf(cB0, cB0, fmaf(cB1, cB1, cB2 * cB2))), sh = sqrtf(fmaf(h0, h0, fmaf(h1, h1, h2 * h2)));
             const bool range_ok = sc - sh > 1e-3f && sc + sh < 1e6f;
@@ -1673,7 +1677,8 @@ extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
         for (int l = 0; l <= ctx->last_rec && l < RT_MAX_LEVELS; ++l)
             fprintf(stderr, "[rt_amd] level %d: %llu pairs, %u listed, %u rays queued\n", l,
                     (unsigned long long)c.n_hits[l] * (unsigned long long)ctx->S.n_shadow_lights, c.n_listed[l], c.n_queued[l]);
-        fprintf(stderr, "[rt_amd] beam traversal trips (flag 0x1000): max %u, total %llu\n", c.dbg_max_trips, c.dbg_sum_trips);
+        fprintf(stderr, "[rt_amd] beam traversal trips (flag 0x1000): max %u, total %llu; pairs to the queue: delicate %u, touched %u, units %u, dedup %u\n",
+                c.dbg_max_trips, c.dbg_sum_trips, c.dbg_why[0], c.dbg_why[1], c.dbg_why[2], c.dbg_why[3]);
         // candidate units of the listed pairs of the LAST level (render with rec_max = 0 to see level 0)
         uint32_t qn[4] = {0, 0, 0, 0};
         (void)hipMemcpy(qn, ctx->beam.queue_n, sizeof(qn), hipMemcpyDeviceToHost);

@@ -206,6 +206,7 @@ struct BeamOut {
     bool occ_all;            // one sphere occludes EVERY ray of the pair (traversal stopped there)
     bool atp_all;            // P lies on a sphere that every ray of the pair leaves through P (not stored in out[])
     uint32_t trips;          // diagnostics: node steps + leaf entries looked at
+    uint32_t why;            // diagnostics: 1 touched list full, 2 candidate units full, 3 dedup list full
 };
 
 // c* / h*: centre and half size of the box of all sample origins, relative to P.  out: the pair record's
@@ -226,7 +227,7 @@ template <int STRIDE>
 __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene &F, uint2 *stk, uint32_t *tl, d3 P, float cB0, float cB1,
                                                 float cB2, float h0, float h1, float h2, const LightQuad &Q, float4 *out, int dbg) {
     BeamOut R;
-    R.nu = 0; R.boxmask = 0; R.overflow = false; R.occ_all = false; R.atp_all = false; R.trips = 0;
+    R.nu = 0; R.boxmask = 0; R.overflow = false; R.occ_all = false; R.atp_all = false; R.trips = 0; R.why = 0;
     const float Pf0 = (float)P.x, Pf1 = (float)P.y, Pf2 = (float)P.z;
     const float Kp = fmaxf(fmaxf(fabsf(Pf0), fabsf(Pf1)), fmaxf(fabsf(Pf2), F.extent));
     const float E = Kp * RT_2M19 + 2e-6f;            // absolute slack on every plane position (and the 1e-6 offsets)
@@ -294,9 +295,22 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
                 const bool touch = !(c0 - rr > bhi0) && !(d0 + rr < blo0) && !(c1 - rr > bhi1) && !(d1 + rr < blo1) &&
                                    !(c2 - rr > bhi2) && !(d2 + rr < blo2);
                 if (touch) {
-                    if (nt < RT_TOUCH) tl[nt * STRIDE] = e;
-                    ++nt;
-                    ntu += sph ? 1u : 2u;
+                    bool in_cone = true;
+                    if (sph && cone_ok) {
+                        // sphere against the cone: distance to the axis <= r (1 + tan) + axial position * tan (conservative).
+                        // The distance comes from the cross product: its error is ~1e-7 |c|, inside the 2e-6 |c| below.
+                        const float ta = fmaf(c0, ax0, fmaf(c1, ax1, c2 * ax2));
+                        const float k0 = fmaf(c1, ax2, -(c2 * ax1)), k1 = fmaf(c2, ax0, -(c0 * ax2)), k2 = fmaf(c0, ax1, -(c1 * ax0));
+                        const float dp2 = fmaf(k0, k0, fmaf(k1, k1, k2 * k2));
+                        const float cn = (fabsf(c0) + fabsf(c1)) + fabsf(c2);         // >= |c|
+                        const float lim = fmaf(lf.r, 1.0f + kt, fmaxf(ta, 0.0f) * kt) + E + 2e-6f * cn;
+                        in_cone = !(dp2 > lim * lim * 1.0001f) && !(ta < -(lf.r + E)) && !(ta > ax_len * (1.0f + kt) + lf.r + E);
+                    }
+                    if (in_cone) {
+                        if (nt < RT_TOUCH) tl[nt * STRIDE] = e;
+                        ++nt;
+                        ntu += sph ? 1u : 2u;
+                    }
                 }
             }
         }
@@ -306,7 +320,7 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
         node = t.x;
         unpack_lambda(t.y, l0, l1);
     }
-    if (nt > RT_TOUCH || ntu > RT_CUNITS + 4u || (dbg & 0x2000)) { R.overflow = true; return R; }
+    if (nt > RT_TOUCH || ntu > RT_CUNITS + 4u || (dbg & 0x2000)) { R.overflow = true; R.why = 1; return R; }
 
     // ---- phase 2: the touched entries.  Cone test, duplicates (a primitive is listed in several leaves),
     // whole-pair verdicts, float64 re-expression.
@@ -320,16 +334,11 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
         const bool sph = kind == 1u;
         const float c0 = lf.x - Pf0, c1 = lf.y - Pf1, c2 = lf.z - Pf2;
         float ta = 0.0f, dp2 = 0.0f, cn = 0.0f;
-        if (sph && cone_ok) {
-            // sphere against the cone: distance to the axis <= r (1 + tan) + axial position * tan (conservative).
-            // The distance comes from the cross product: its error is ~1e-7 |c|, inside the 2e-6 |c| below.
+        if (sph && cone_ok) {                        // (passed the cone test in phase 1)
             ta = fmaf(c0, ax0, fmaf(c1, ax1, c2 * ax2));
             const float k0 = fmaf(c1, ax2, -(c2 * ax1)), k1 = fmaf(c2, ax0, -(c0 * ax2)), k2 = fmaf(c0, ax1, -(c1 * ax0));
             dp2 = fmaf(k0, k0, fmaf(k1, k1, k2 * k2));
             cn = (fabsf(c0) + fabsf(c1)) + fabsf(c2);                             // >= |c|
-            const float lim = fmaf(lf.r, 1.0f + kt, fmaxf(ta, 0.0f) * kt) + E + 2e-6f * cn;
-            const bool in_cone = !(dp2 > lim * lim * 1.0001f) && !(ta < -(lf.r + E)) && !(ta > ax_len * (1.0f + kt) + lf.r + E);
-            if (!in_cone) continue;
         }
         bool seen = false;
 #pragma unroll
@@ -368,7 +377,7 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
             }
         }
         if (store) {
-            if (nu + kind > RT_CUNITS) { R.overflow = true; return R; }          // kind == units needed (sphere 1, box 2)
+            if (nu + kind > RT_CUNITS) { R.overflow = true; R.why = 2; return R; }          // kind == units needed (sphere 1, box 2)
             if (sph) {
                 out[nu] = make_float4((float)dx, (float)dy, (float)dz, (float)cd);
                 nu += 1;
@@ -380,7 +389,7 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
                 nu += 2;
             }
         }
-        if (n >= RT_CMAX) { R.overflow = true; return R; }                       // the dedup list is full
+        if (n >= RT_CMAX) { R.overflow = true; R.why = 3; return R; }                       // the dedup list is full
 #pragma unroll
         for (uint32_t j = 0; j < RT_CMAX; ++j) if (j == n) ids[j] = prim;
         ++n;
