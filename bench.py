@@ -14,7 +14,8 @@ inputs (scene, BSP tree) resident in HBM before the timed region.
 value = rays handed to the nearest-hit query per second, counted exactly as the
 reference counts them (every ray given to BSPNode.intersect_vectorize), whole job.
 
-Rank 0 prints ONE JSON line with the roofline of the dominant kernel (k_shadow)
+Rank 0 prints ONE JSON line with the roofline of the dominant kernel family (soft shadows:
+k_beam_setup + k_shadow_beam + k_shadow_queue, timed with HIP events on the launch stream)
 and the CPU baseline (the float64 oracle, timed on a bounded sub-sampled frame).
 """
 import argparse
@@ -195,7 +196,7 @@ def main():
         ms_shadow = prof["ms_shadow"]
         achieved = shadow_flops / (ms_shadow * 1e-3) / 1e12 if ms_shadow > 0 else 0.0
         roofline = {
-            "bound": "valu", "kernel": "k_shadow", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS,
+            "bound": "valu", "kernel": "soft shadows: k_beam_setup + k_shadow_beam + k_shadow_queue", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": None,
             "launches": prof["launches_per_family"], "kernel_ms_per_frame": round(ms_shadow, 3),
             "algorithmic_flops_per_shadow_ray": round(flops_per_shadow_ray, 1),
@@ -220,7 +221,7 @@ def main():
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
-            "dtype": "f64 decisions + f64 shading (f32 only for culling)", "data": "synthetic",
+            "dtype": "f64 (decisions, hit points, shading); f32 filtered predicates with f64 fallback", "data": "synthetic",
             "config": {"workload": "%s %dx%d, %dx%d shadow rays, recursion %d, jitter %s" % (
                 args.workload, W, H, sh_used, sh_used, rec_used, "on" if jitter else "off"),
                 "primitives": scene.packed.desc.n_spheres + scene.packed.desc.n_boxes + scene.packed.desc.n_planes,
