@@ -24,6 +24,7 @@
 
 #include <string>
 #include <vector>
+#include <algorithm>
 
 #include "../../include/rt_amd.h"
 #include "rt_device.hpp"
@@ -86,24 +87,24 @@ struct LevelParams {
     int32_t beam;                        // this frame's soft shadows go through the beam path
 };
 
-// XCD-aware chunk walk: workgroups b and b+8 share an XCD (and its L2), so XCD x = b % 8 walks one
-// contiguous eighth of the queue - rays that are neighbours in the queue (= in the image) keep
-// hitting the same L2.  A chunk is RT_BLOCK consecutive items.  Speed only, never correctness.
+// XCD-aware chunk walk.  A chunk is RT_BLOCK consecutive items; chunks are dealt to the 8 XCDs in groups of
+// RT_XCD_GROUP (group g -> XCD g % 8; workgroups b and b+8 share an XCD and its L2): items that are neighbours in
+// the queue (= in the image) keep hitting the same L2, and every XCD still sees every part of the image - a
+// contiguous eighth per XCD left the XCDs that drew sky idle while the one with the horizon worked.
+// Within its XCD, workgroup j of nb takes the XCD's chunks j, j + nb, j + 2 nb, ...  Speed only, never correctness.
+#define RT_XCD_GROUP 8u
 struct ChunkWalk {
-    uint32_t per, pos, step, base, nchunks;
+    uint32_t m, step, xcd, nchunks;
     __device__ ChunkWalk(uint64_t n_items) {
         nchunks = (uint32_t)((n_items + RT_BLOCK - 1) / RT_BLOCK);
-        per = (nchunks + 7u) >> 3;
-        uint32_t xcd = blockIdx.x & 7u;
-        base = xcd * per;
-        pos = blockIdx.x >> 3;
-        step = gridDim.x >> 3;
+        xcd = blockIdx.x & 7u;
+        m = blockIdx.x >> 3;                 // index among the XCD's chunks
+        step = gridDim.x >> 3;               // workgroups per XCD (grids are multiples of 8)
     }
     __device__ bool next(uint64_t &first_item) {
-        if (pos >= per) return false;
-        uint32_t c = base + pos;
-        pos += step;
-        if (c >= nchunks) return false;
+        const uint32_t c = ((m / RT_XCD_GROUP) * 8u + xcd) * RT_XCD_GROUP + (m % RT_XCD_GROUP);
+        m += step;
+        if (c >= nchunks) return false;      // c grows with m: nothing further either
         first_item = (uint64_t)c * RT_BLOCK;
         return true;
     }
@@ -618,8 +619,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
     // would otherwise also wait for them (one vmcnt) - : lane l of the wave parks the ballot of iteration
     // 64 w + l, and the wave stores 64 of them at once.
     unsigned long long keep = 0ull;
-    uint32_t it = 0u, win_chunk = 0u;
-    const uint32_t cstep = walk.step;
+    uint32_t it = 0u, keep_chunk = 0u;
     float pn[RT_PMAX][3];
     for (int k = 0; k < RT_PMAX; ++k)
         for (int c = 0; c < 3; ++c) pn[k][c] = k < S.n_planes ? (float)S.planes[k].n[c] : 0.0f;
@@ -752,14 +752,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
             }
         }
         const unsigned long long lm = __ballot(lit);
-        if ((it & 63u) == 0u) win_chunk = cur;
-        if ((uint32_t)lane == (it & 63u)) keep = lm;
+        if ((uint32_t)lane == (it & 63u)) { keep = lm; keep_chunk = cur; }
         ++it;
-        if ((it & 63u) == 0u) bb.litbits[((uint64_t)win_chunk + (uint64_t)lane * cstep) * (RT_BLOCK / 64) + wave] = keep;
+        if ((it & 63u) == 0u) bb.litbits[(uint64_t)keep_chunk * (RT_BLOCK / 64) + wave] = keep;
         cur = nxt; pno_cur = pno_nxt; have = have_n;
         nxt = n2; pno_nxt = pno_n2; have_n = have_n2;
     }
-    if ((uint32_t)lane < (it & 63u)) bb.litbits[((uint64_t)win_chunk + (uint64_t)lane * cstep) * (RT_BLOCK / 64) + wave] = keep;
+    if ((uint32_t)lane < (it & 63u)) bb.litbits[(uint64_t)keep_chunk * (RT_BLOCK / 64) + wave] = keep;
     if (qn) {                                        // the rest of the wave's undecided rays
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();

@@ -174,9 +174,13 @@ __device__ __forceinline__ void fast_nearest(const DScene &S, const FastScene &F
         }
         // ---- leaf ----
         {
-            const uint32_t first = nd.a, cnt = nd.b >> 2;
-            for (uint32_t e = first; e < first + cnt; ++e) {
-                const LeafF lf = F.leaves[e];
+            // the next entry's record is requested before the current one is looked at: a leaf costs about
+            // one memory round trip per two entries instead of one per entry (this loop is latency bound)
+            const uint32_t first = nd.a, last = nd.a + (nd.b >> 2) - 1u;
+            LeafF nxt = F.leaves[first];
+            for (uint32_t e = first; e <= last; ++e) {
+                const LeafF lf = nxt;
+                nxt = F.leaves[e < last ? e + 1u : last];
                 const uint32_t kind = lf.pk & 3u, prim = lf.pk >> 2;
                 const float tcur = st.tbest;
                 bool cand;

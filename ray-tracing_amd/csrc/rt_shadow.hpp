@@ -285,8 +285,10 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
             const float blo1 = fminf(m0 * L1, m1 * L1) - E, bhi1 = fmaxf(m0 * U1, m1 * U1) + E;
             const float blo2 = fminf(m0 * L2, m1 * L2) - E, bhi2 = fmaxf(m0 * U2, m1 * U2) + E;
             const uint32_t e_end = nd.a + (nd.b >> 2);
+            LeafF nxt = F.leaves[nd.a];                  // one entry ahead: the loop is bound by memory latency
             for (uint32_t e = nd.a; e < e_end && nt <= RT_TOUCH && ntu <= RT_CUNITS + 4u; ++e) {   // (leaves at the depth limit hold hundreds of entries)
-                const LeafF lf = F.leaves[e];
+                const LeafF lf = nxt;
+                nxt = F.leaves[e + 1u < e_end ? e + 1u : e];
                 ++R.trips;
                 const bool sph = (lf.pk & 3u) == 1u;     // sphere {centre, r, (low parts)}; box {lo, -, hi}
                 const float rr = sph ? lf.r : 0.0f;
