@@ -5,6 +5,8 @@ against the CPU oracle on the same seeded inputs.
 Bars (BASELINE.json north_star): hit ids bit-exact; deterministic frames within
 1/255 per pixel on 8-bit output (we observe 0); float64 hit points bit-exact
 where the reference does not go through BLAS."""
+import os
+
 import numpy as np
 import pytest
 
@@ -219,3 +221,77 @@ def test_fast_intersect_axis_parallel_and_degenerate_rays(gpu_ctx, oracle):
     opts, oids, _ = oracle.intersect(sc["packed"], o, d)
     assert np.array_equal(ids, oids)
     assert np.array_equal(pts, opts, equal_nan=True)
+
+
+# ------------------------------------------------------------------ whole-pair shadow verdicts under stress
+def _stress_scene(kind):
+    """Sphere fields with lights chosen to exercise every branch of the beam path: wide penumbrae (large light
+    close to the field), hard shadows (umbra verdicts), a light inside the field (cone test disabled, samples
+    inside primitives), tiny and huge spheres, terminators on large spheres, boxes mixed in."""
+    rng = np.random.default_rng(11)
+    L = ["cam 0 6 -14 0 0.5 0 0 1 0 1.3 1", "set 0.2 0.3 0.5 5 3",
+         "mtl 0.8 0.3 0.3 0.9 0.9 0.9 0.2 0.2 0.2 30 0", "mtl 0.3 0.8 0.3 0.4 0.4 0.4 0 0 0 8 0",
+         "mtl 0.5 0.5 0.6 0.1 0.1 0.1 0 0 0 2 0", "mtl 0.4 0.4 0.9 0.7 0.7 0.7 0 0 0 12 0.5",
+         "pln 0 1 0 -1 3"]
+    for ix in range(12):
+        for iz in range(12):
+            c = [ix - 5.5 + rng.uniform(-0.2, 0.2), -1 + rng.uniform(0.2, 1.6), iz - 5.5 + rng.uniform(-0.2, 0.2)]
+            r = float(rng.uniform(0.05, 0.45))
+            if kind == "boxes" and (ix + iz) % 3 == 0:
+                L.append("box %r %r %r %r %d" % (c[0], c[1], c[2], 2 * r, 1 + (ix + iz) % 4))
+            else:
+                L.append("sph %r %r %r %r %d" % (c[0], c[1], c[2], r, 1 + (ix * 7 + iz) % 4))
+    L.append("sph 0 2.5 3 2.2 1")                                     # huge sphere: long terminator, big umbra
+    L.append("sph 2 -0.97 -3 0.03 2")                                 # tiny sphere touching the ground
+    if kind == "wide":
+        L += ["lgt 0 7 -2 1 1 1 1 0.9 6", "lgt -6 3 -6 0.6 0.6 0.8 1 0.7 3"]
+    elif kind == "hard":
+        L += ["lgt 30 60 -40 1 1 1 1 1 0.05", "lgt -40 25 10 0.5 0.5 0.5 1 0.8 0.3"]
+    elif kind == "inside":
+        L += ["lgt 0.3 0.4 0.2 1 1 1 1 0.9 1.5", "lgt 0 12 0 0.5 0.5 0.5 1 0.5 2", "lgt 3 -0.9 -2 0.4 0.4 0.4 1 0.8 0.4"]
+    else:
+        L += ["lgt 2 9 -5 1 1 1 1 0.9 2", "lgt -7 5 3 0.6 0.6 0.6 1 0.6 1"]
+    return "\n".join(L) + "\n"
+
+
+_STRESS = {}
+
+
+def _stress_ctx(kind):
+    if kind not in _STRESS:
+        import tempfile
+        from ray_tracing_amd.render import Scene
+        with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+            f.write(_stress_scene(kind))
+        try:
+            sc = Scene.from_file(f.name)
+        finally:
+            os.unlink(f.name)
+        _STRESS[kind] = (sc, native.Context(sc.packed, device=0))
+    return _STRESS[kind][1]
+
+
+@pytest.mark.parametrize("kind,sh,jitter", [("wide", 5, True), ("wide", 3, False), ("hard", 5, True), ("hard", 16, True),
+                                            ("inside", 4, True), ("inside", 7, False), ("boxes", 5, True),
+                                            ("boxes", 3, True), ("plain", 9, True)])
+def test_beam_path_equals_exact_walk_under_stress(kind, sh, jitter):
+    """Whole-pair verdicts (umbra, own sphere at the terminator, quad miss test), the per-ray float32 predicates and
+    the float64 queue together must give the frame of the exact walk, bit for bit (float64 sums -> float32)."""
+    ctx = _stress_ctx(kind)
+    w, h = (160, 90) if sh >= 9 else (256, 144)
+    common = dict(sh_rays=sh, rec_max=3, jitter=jitter, seed=7)
+    exact = ctx.render(abi.render_params(w, h, flags=abi.RT_FLAG_EXACT_TRAVERSAL, **common))
+    fast = ctx.render(abi.render_params(w, h, **common))
+    assert np.array_equal(fast["ids"], exact["ids"])
+    assert fast["stats"]["rays"] == exact["stats"]["rays"]
+    assert np.array_equal(fast["rgb"], exact["rgb"])
+
+
+def test_beam_path_frame_matches_oracle_on_stress_scene(oracle):
+    ctx = _stress_ctx("wide")
+    p = abi.render_params(128, 72, sh_rays=5, rec_max=2, jitter=True, seed=3)
+    out = ctx.render(p)
+    ref = oracle.render(_STRESS["wide"][0].packed, p)
+    assert np.array_equal(out["ids"], ref["ids"])
+    assert np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
+    assert out["stats"]["shadow_rays"] == ref["counters"]["shadow_rays"]
