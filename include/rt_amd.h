@@ -137,6 +137,8 @@ typedef struct rt_render_params {
                                       (no float32 culling, no pruning); results must be identical */
 #define RT_FLAG_NO_BEAM 4          /* diagnostic: decide every shadow ray with its own float64-confirmed traversal
                                       instead of the per-(hit,light) beam + float32 filtered predicates */
+#define RT_FLAG_NO_OVERLAP 8       /* diagnostic: run the recursion levels strictly one after the other (the default lets the
+                                      deeper levels run beside the soft shadows of level 0); same result */
 #define RT_FLAG_PROFILE 2          /* bracket every kernel launch with HIP events on the launch stream and
                                       report per-family device time in rt_stats (used by bench.py's roofline) */
 

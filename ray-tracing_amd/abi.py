@@ -8,6 +8,7 @@ RT_SURF_BACKGROUND, RT_SURF_SPHERE, RT_SURF_BOX, RT_SURF_PLANE = 0, 1, 2, 3
 RT_FLAG_EXACT_TRAVERSAL = 1
 RT_FLAG_PROFILE = 2
 RT_FLAG_NO_BEAM = 4
+RT_FLAG_NO_OVERLAP = 8
 
 RT_OK = 0
 STATUS_NAMES = {0: "RT_OK", -1: "RT_ERR_INVALID_ARG", -2: "RT_ERR_NO_DEVICE", -3: "RT_ERR_HIP", -4: "RT_ERR_OOM",

@@ -791,11 +791,16 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_queue(DScene S, FastScene F
     }
 }
 
-// Phong shading + secondary-ray generation for every hit of the level
+// Phong shading (MODE & 1) + secondary-ray generation (MODE & 2) for every hit of the level.  The two halves are
+// separate launches at level 0 when the frame overlaps its levels: the children only need the hit, not the
+// lit counts, so level 1 can start while level 0's soft shadows are still being decided.
+#define RT_SHADE_LIGHTS 1
+#define RT_SHADE_SPAWN 2
+template <int MODE>
 __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, LevelParams lp, RayQ q, RayQ qn, HitBuf hb, FrameCtl *ctl,
                                                     double *fb, const unsigned long long *litbits, const uint32_t *pair_slot, const uint32_t *queue_n) {
     if (ctl->overflow) return;
-    if (lp.beam && blockIdx.x == 0 && threadIdx.x == 0) { ctl->n_queued[lp.level] = queue_n[0]; ctl->n_listed[lp.level] = queue_n[1]; }
+    if ((MODE & RT_SHADE_LIGHTS) && lp.beam && blockIdx.x == 0 && threadIdx.x == 0) { ctl->n_queued[lp.level] = queue_n[0]; ctl->n_listed[lp.level] = queue_n[1]; }
     const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
     const uint32_t nsl = (uint32_t)S.n_shadow_lights;
     const double s2 = (double)(lp.sh_rays * lp.sh_rays);
@@ -830,7 +835,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, LevelParams lp, Ra
             d3 Nh = N / norm3(N);                                        // ray_functions.py:98-99
             d3 diff = mk3(0, 0, 0), spec = mk3(0, 0, 0);
             uint32_t ml = 0;
-            for (int m = 0; m < S.n_lights; ++m) {
+            for (int m = 0; (MODE & RT_SHADE_LIGHTS) && m < S.n_lights; ++m) {
                 const DLight &Lt = S.lights[m];
                 d3 dl = ld3(Lt.pos) - P;                                 // Light.py:35-53
                 d3 L = dl / norm3(dl);
@@ -877,7 +882,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, LevelParams lp, Ra
             spec = mk3(nan_to_num(spec.x), nan_to_num(spec.y), nan_to_num(spec.z));   // Light.py:173
             double nt = 1.0 - T;
             d3 base = (diff + spec) * mk3(nt, nt, nt);                   // ray_tracer.py:105-106
-            fb_add(fb, slot, thr * base);
+            if (MODE & RT_SHADE_LIGHTS) fb_add(fb, slot, thr * base);
+            if (!(MODE & RT_SHADE_SPAWN)) mflags = 0;
             if (mflags & 1) {                                            // ray_tracer.py:108-116
                 thr_t = thr * mk3(T, T, T);
                 if (lp.last_level) fb_add(fb, slot, thr_t * ld3(S.bg));  // child returns background (:62-63)
@@ -943,9 +949,11 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, LevelParams lp, Ra
 }
 
 // clip(0,1) (ray_tracer.py:30) and save_image's truncating quantisation (util.py:98)
-__global__ void __launch_bounds__(RT_BLOCK) k_resolve(const double *fb, uint64_t n_values, float *rgb, uint8_t *rgb8) {
+// fb0: what the level-0 rays add themselves (background of the misses, Phong term of the hits); fb: everything the
+// deeper levels add.  Two buffers keep the sum independent of how the two halves of the frame are scheduled.
+__global__ void __launch_bounds__(RT_BLOCK) k_resolve(const double *fb, const double *fb0, uint64_t n_values, float *rgb, uint8_t *rgb8) {
     for (uint64_t k = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x; k < n_values; k += (uint64_t)gridDim.x * RT_BLOCK) {
-        double v = fb[k];
+        double v = fb0[k] + fb[k];
         double c = v < 0 ? 0 : (v > 1 ? 1 : v);
         if (rgb) rgb[k] = (float)c;
         if (rgb8) rgb8[k] = isnan(c) ? (uint8_t)0 : (uint8_t)(c * 255);
@@ -1042,9 +1050,14 @@ struct rt_ctx {
     uint64_t fb_slots = 0;
     double growth = 2.0;    // queue capacity = growth * primary slots
     std::vector<void *> frame_allocs;
-    RayQ q[2]{};
-    HitBuf hb{};
-    double *fb = nullptr;
+    RayQ q[3]{};            // level 0 -> q[0]; level k >= 1 -> q[1 + (k - 1) % 2]
+    HitBuf hb{}, hb1{};     // level 0 / deeper levels (so are seg, beam and seg1, beam1)
+    SegBuf seg1{};
+    BeamBuf beam1{};
+    double *fb = nullptr, *fb0 = nullptr;   // see k_resolve
+    hipStream_t stream2 = nullptr;          // the deeper levels of an overlapped frame
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int nb_intersect = 1, nb_beam_setup = 1, nb_beam = 1, nb_queue = 1, nb_shade = 1, nb_setup = 1, nb_shadow = 1;   // workgroups per CU
     FrameCtl *ctl = nullptr;
     FrameCtl *h_ctl = nullptr;   // pinned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1155,6 +1168,9 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
     HIP_C(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIP_C(hipEventCreate(&ctx->ev0));
     HIP_C(hipEventCreate(&ctx->ev1));
+    HIP_C(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    HIP_C(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    HIP_C(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     HIP_C(hipMalloc((void **)&ctx->ctl, sizeof(FrameCtl)));
     HIP_C(hipHostMalloc((void **)&ctx->h_ctl, sizeof(FrameCtl), hipHostMallocDefault));
     hipDeviceProp_t prop;
@@ -1304,24 +1320,26 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
     // grid; a second, partially filled round of workgroups would run at a fraction of the occupancy) ----
     {
         const char *ov = getenv("RT_AMD_BLOCKS_PER_CU");
+        int last_nb = 1;
         auto grid_for = [&](const void *fn, size_t lds) {
             int nb = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, RT_BLOCK, lds) != hipSuccess || nb < 1) nb = 1;
             if (nb > 6) nb = 6;       // ~100 SGPRs per wave admit 6 workgroups of 256 per CU (MI355X_MICROARCH.md, residency)
             if (ov && atoi(ov) > 0) nb = atoi(ov);
+            last_nb = nb;
             int g = ctx->n_cu * nb;
             return (g + 7) & ~7;
         };
         const size_t lds = ctx->lds_bytes;
-        ctx->g_intersect = grid_for((const void *)&k_intersect<true>, lds);
+        ctx->g_intersect = grid_for((const void *)&k_intersect<true>, lds); ctx->nb_intersect = last_nb;
         ctx->g_intersect_x = grid_for((const void *)&k_intersect<false>, 0);
-        ctx->g_shadow = grid_for((const void *)&k_shadow<true>, lds);
+        ctx->g_shadow = grid_for((const void *)&k_shadow<true>, lds); ctx->nb_shadow = last_nb;
         ctx->g_shadow_x = grid_for((const void *)&k_shadow<false>, 0);
-        ctx->g_beam_setup = grid_for((const void *)&k_beam_setup, lds);
-        ctx->g_beam = grid_for((const void *)&k_shadow_beam, 0);
-        ctx->g_queue = grid_for((const void *)&k_shadow_queue, lds);
-        ctx->g_shade = grid_for((const void *)&k_shade, 0);
-        ctx->g_setup = grid_for((const void *)&k_shadow_setup, 0);
+        ctx->g_beam_setup = grid_for((const void *)&k_beam_setup, lds); ctx->nb_beam_setup = last_nb;
+        ctx->g_beam = grid_for((const void *)&k_shadow_beam, 0); ctx->nb_beam = last_nb;
+        ctx->g_queue = grid_for((const void *)&k_shadow_queue, lds); ctx->nb_queue = last_nb;
+        ctx->g_shade = grid_for((const void *)&k_shade<3>, 0); ctx->nb_shade = last_nb;
+        ctx->g_setup = grid_for((const void *)&k_shadow_setup, 0); ctx->nb_setup = last_nb;
         if (getenv("RT_AMD_DEBUG"))
             fprintf(stderr, "[rt_amd] grids: intersect %d beam_setup %d beam %d queue %d shade %d\n", ctx->g_intersect,
                     ctx->g_beam_setup, ctx->g_beam, ctx->g_queue, ctx->g_shade);
@@ -1383,6 +1401,7 @@ static void free_frame(rt_ctx *ctx) {
     ctx->cap = 0;
     ctx->fb_slots = 0;
     ctx->fb = nullptr;
+    ctx->fb0 = nullptr;
 }
 
 extern "C" int rt_destroy(rt_ctx *ctx) {
@@ -1396,6 +1415,9 @@ extern "C" int rt_destroy(rt_ctx *ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RT_OK;
@@ -1419,33 +1441,35 @@ static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
     free_frame(ctx);
     uint64_t cap = want_cap;
 #define TRY_A(expr) do { int rc_ = (expr); if (rc_ != RT_OK) { free_frame(ctx); return rc_; } } while (0)
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {
         RayQ &q = ctx->q[i];
         TRY_A(dalloc(ctx, &q.ox, cap)); TRY_A(dalloc(ctx, &q.oy, cap)); TRY_A(dalloc(ctx, &q.oz, cap));
         TRY_A(dalloc(ctx, &q.dx, cap)); TRY_A(dalloc(ctx, &q.dy, cap)); TRY_A(dalloc(ctx, &q.dz, cap));
         TRY_A(dalloc(ctx, &q.tr, cap)); TRY_A(dalloc(ctx, &q.tg, cap)); TRY_A(dalloc(ctx, &q.tb, cap));
         TRY_A(dalloc(ctx, &q.slot, cap)); TRY_A(dalloc(ctx, &q.gpix, cap)); TRY_A(dalloc(ctx, &q.path, cap));
     }
-    HitBuf &hb = ctx->hb;
-    TRY_A(dalloc(ctx, &hb.px, cap)); TRY_A(dalloc(ctx, &hb.py, cap)); TRY_A(dalloc(ctx, &hb.pz, cap));
-    TRY_A(dalloc(ctx, &hb.id, cap)); TRY_A(dalloc(ctx, &hb.list, cap));
     uint64_t nlit = cap * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1);
-    TRY_A(dalloc(ctx, &hb.lit, nlit));
-    HIP_TRY(ctx, hipMemsetAsync(hb.lit, 0, nlit * sizeof(uint32_t), ctx->stream));
-    SegBuf &sg = ctx->seg;
-    TRY_A(dalloc(ctx, &sg.ux, nlit)); TRY_A(dalloc(ctx, &sg.uy, nlit)); TRY_A(dalloc(ctx, &sg.uz, nlit));
-    TRY_A(dalloc(ctx, &sg.rx, nlit)); TRY_A(dalloc(ctx, &sg.ry, nlit)); TRY_A(dalloc(ctx, &sg.rz, nlit));
-    TRY_A(dalloc(ctx, &sg.cx, nlit)); TRY_A(dalloc(ctx, &sg.cy, nlit)); TRY_A(dalloc(ctx, &sg.cz, nlit));
-    BeamBuf &bb = ctx->beam;
     ctx->beam_queue_cap = (uint32_t)(cap < 0x7fffffffull ? cap : 0x7fffffffull);
-    TRY_A(dalloc(ctx, &bb.rec, (nlit + RT_BLOCK) * RT_PAIR_UNITS));   // + one chunk of slack: staging reads whole chunks
-    TRY_A(dalloc(ctx, &bb.queue, (uint64_t)ctx->beam_queue_cap)); TRY_A(dalloc(ctx, &bb.queue_n, 4));
-    TRY_A(dalloc(ctx, &bb.litbits, (nlit + 1) * (RT_BLOCK / 64)));      // worst case one pair per chunk (s*s > RT_BLOCK / 2)
-    TRY_A(dalloc(ctx, &bb.list, nlit)); TRY_A(dalloc(ctx, &bb.pair_slot, nlit));
-    {
+    for (int set = 0; set < 2; ++set) {          // level 0 / deeper levels: the two halves of an overlapped frame
+        HitBuf &hb = set ? ctx->hb1 : ctx->hb;
+        TRY_A(dalloc(ctx, &hb.px, cap)); TRY_A(dalloc(ctx, &hb.py, cap)); TRY_A(dalloc(ctx, &hb.pz, cap));
+        TRY_A(dalloc(ctx, &hb.id, cap)); TRY_A(dalloc(ctx, &hb.list, cap));
+        TRY_A(dalloc(ctx, &hb.lit, nlit));
+        HIP_TRY(ctx, hipMemsetAsync(hb.lit, 0, nlit * sizeof(uint32_t), ctx->stream));
+        SegBuf &sg = set ? ctx->seg1 : ctx->seg;
+        TRY_A(dalloc(ctx, &sg.ux, nlit)); TRY_A(dalloc(ctx, &sg.uy, nlit)); TRY_A(dalloc(ctx, &sg.uz, nlit));
+        TRY_A(dalloc(ctx, &sg.rx, nlit)); TRY_A(dalloc(ctx, &sg.ry, nlit)); TRY_A(dalloc(ctx, &sg.rz, nlit));
+        TRY_A(dalloc(ctx, &sg.cx, nlit)); TRY_A(dalloc(ctx, &sg.cy, nlit)); TRY_A(dalloc(ctx, &sg.cz, nlit));
+        BeamBuf &bb = set ? ctx->beam1 : ctx->beam;
+        TRY_A(dalloc(ctx, &bb.rec, (nlit + RT_BLOCK) * RT_PAIR_UNITS));   // + one chunk of slack: staging reads whole chunks
+        TRY_A(dalloc(ctx, &bb.queue, (uint64_t)ctx->beam_queue_cap)); TRY_A(dalloc(ctx, &bb.queue_n, 4));
+        TRY_A(dalloc(ctx, &bb.litbits, (nlit + 1) * (RT_BLOCK / 64)));      // worst case one pair per chunk (s*s > RT_BLOCK / 2)
+        TRY_A(dalloc(ctx, &bb.list, nlit)); TRY_A(dalloc(ctx, &bb.pair_slot, nlit));
         uint32_t init[4] = {0u, 0u, ctx->beam_queue_cap, 0u};
         HIP_TRY(ctx, hipMemcpy(bb.queue_n, init, sizeof(init), hipMemcpyHostToDevice));
     }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    TRY_A(dalloc(ctx, &ctx->fb0, slots * 3));
     TRY_A(dalloc(ctx, &ctx->fb, slots * 3));
 #undef TRY_A
     ctx->cap = cap;
@@ -1525,17 +1549,25 @@ static int prof_prepare(rt_ctx *ctx, int levels) {
 }
 #define PROF_MARK(idx) do { if (prof) HIP_TRY(ctx, hipEventRecord(ctx->prof_ev[(idx)], st)); } while (0)
 
-// enqueue levels 0..rec on the stream; queue 0 must hold the level-0 rays
-static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, int32_t rec, int32_t *d_ids, hipStream_t st) {
+// enqueue levels 0..rec; queue 0 must hold the level-0 rays.  fb0 receives what the level-0 rays add themselves.
+//
+// Overlapped schedule (fb0 != fb, rec >= 1, no profiling): the deeper levels hold few rays but long ones (reflections
+// skimming through the field) - their kernels are latency chains that leave the GPU idle, ~1/3 of a sequential
+// frame.  Level 0's children only need the hits, so after k_intersect(0) the frame forks:
+//     st      : soft shadows of level 0 -> Phong term of level 0 (fb0)                 [hb, seg, beam, q[0] read-only]
+//     stream2 : children of level 0 -> levels 1..rec complete (fb)                     [hb1, seg1, beam1, q[1], q[2]]
+// and joins before the resolve.  Both sides use fixed grids; the level-0 side leaves one workgroup slot per CU to
+// the other.  Results do not depend on the schedule: the two sides add into different framebuffers.
+static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, int32_t rec, int32_t *d_ids, hipStream_t st,
+                          double *fb0) {
     LevelParams lp{};
     lp.sh_rays = sh; lp.jitter = p->jitter; lp.seed = p->seed; lp.cap = (uint32_t)ctx->cap; lp.flags = p->flags;
-    dim3 grid(ctx->grid), block(RT_BLOCK);
+    dim3 block(RT_BLOCK);
     const bool prof = (p->flags & RT_FLAG_PROFILE) != 0;
     const bool fast = ctx->F.ok && !(p->flags & RT_FLAG_EXACT_TRAVERSAL);
     const uint32_t s2 = (uint32_t)(sh * sh);
     const bool beam = fast && ctx->S.n_planes <= RT_PMAX && !(p->flags & RT_FLAG_NO_BEAM) && s2 >= 9 && s2 <= RT_BLOCK &&
                       ctx->S.n_lights <= 256 &&   // pair record: 8-bit light index
-
                       ctx->cap * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1) < 0xFFFFFFFFull;
     if (s2 > 0 && s2 <= RT_BLOCK) {
         lp.spb = RT_BLOCK / s2;
@@ -1543,32 +1575,83 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         lp.magic_s2 = (uint32_t)((0x100000000ull + s2 - 1) / s2);
         lp.magic_s = (uint32_t)((0x100000000ull + (uint32_t)sh - 1) / (uint32_t)sh);
     }
-    for (int level = 0; level <= rec; ++level) {
+    const bool overlap = fast && !prof && rec >= 1 && fb0 != ctx->fb && !(p->flags & RT_FLAG_NO_OVERLAP) && ctx->n_cu >= 8;
+    static const int ovl_main = getenv("RT_AMD_OVL_MAIN") ? atoi(getenv("RT_AMD_OVL_MAIN")) : 3;   // workgroups per CU, level-0 side
+    static const int ovl_side = getenv("RT_AMD_OVL_SIDE") ? atoi(getenv("RT_AMD_OVL_SIDE")) : 1;   // deeper levels
+    // grid of a kernel with nb workgroups per CU at full occupancy: side 0 = sequential, 1 = level-0 side, 2 = deeper levels
+    auto gsz = [&](int full, int nb, int side) {
+        if (!overlap || side == 0) return full;
+        int lim = side == 1 ? ovl_main : ovl_side;
+        int use = nb < lim ? nb : lim;
+        if (use < 1) use = 1;
+        return (ctx->n_cu * use + 7) & ~7;
+    };
+    auto shadows = [&](int level, hipStream_t s_, RayQ &qc, HitBuf &hb, SegBuf &sg, BeamBuf &bb, int side) -> int {
         lp.level = level;
         lp.last_level = (level == rec) ? 1 : 0;
-        RayQ &qc = ctx->q[level & 1], &qn = ctx->q[(level + 1) & 1];
-        const int e = 2 + 6 * level;
-        PROF_MARK(e + 0);
-        if (fast) hipLaunchKernelGGL(k_intersect<true>, dim3(ctx->g_intersect), block, ctx->lds_bytes, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->ctl, ctx->fb, d_ids);
-        else hipLaunchKernelGGL(k_intersect<false>, dim3(ctx->g_intersect_x), block, 0, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->ctl, ctx->fb, d_ids);
-        PROF_MARK(e + 1);
-        PROF_MARK(e + 2);
-        if (ctx->S.n_shadow_lights > 0) {
-            if (beam) {
-                HIP_TRY(ctx, hipMemsetAsync(ctx->beam.queue_n, 0, 2 * sizeof(uint32_t), st));
-                hipLaunchKernelGGL(k_beam_setup, dim3(ctx->g_beam_setup), block, ctx->lds_bytes, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->beam, ctx->ctl);
-                hipLaunchKernelGGL(k_shadow_beam, dim3(ctx->g_beam), block, 0, st, ctx->S, lp, ctx->hb, ctx->beam, ctx->ctl);
-                hipLaunchKernelGGL(k_shadow_queue, dim3(ctx->g_queue), block, ctx->lds_bytes, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->seg, ctx->beam, ctx->ctl);
-            } else {
-                hipLaunchKernelGGL(k_shadow_setup, dim3(ctx->g_setup), block, 0, st, ctx->S, lp, ctx->hb, ctx->seg, ctx->ctl);
-                if (fast) hipLaunchKernelGGL(k_shadow<true>, dim3(ctx->g_shadow), block, ctx->lds_bytes, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->seg, ctx->ctl);
-                else hipLaunchKernelGGL(k_shadow<false>, dim3(ctx->g_shadow_x), block, 0, st, ctx->S, ctx->F, lp, qc, ctx->hb, ctx->seg, ctx->ctl);
-            }
+        if (ctx->S.n_shadow_lights <= 0) return RT_OK;
+        if (beam) {
+            HIP_TRY(ctx, hipMemsetAsync(bb.queue_n, 0, 2 * sizeof(uint32_t), s_));
+            hipLaunchKernelGGL(k_beam_setup, dim3(gsz(ctx->g_beam_setup, ctx->nb_beam_setup, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
+            hipLaunchKernelGGL(k_shadow_beam, dim3(gsz(ctx->g_beam, ctx->nb_beam, side)), block, 0, s_, ctx->S, lp, hb, bb, ctx->ctl);
+            hipLaunchKernelGGL(k_shadow_queue, dim3(gsz(ctx->g_queue, ctx->nb_queue, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, sg, bb, ctx->ctl);
+        } else {
+            hipLaunchKernelGGL(k_shadow_setup, dim3(gsz(ctx->g_setup, ctx->nb_setup, side)), block, 0, s_, ctx->S, lp, hb, sg, ctx->ctl);
+            if (fast) hipLaunchKernelGGL(k_shadow<true>, dim3(gsz(ctx->g_shadow, ctx->nb_shadow, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, sg, ctx->ctl);
+            else hipLaunchKernelGGL(k_shadow<false>, dim3(ctx->g_shadow_x), block, 0, s_, ctx->S, ctx->F, lp, qc, hb, sg, ctx->ctl);
         }
-        PROF_MARK(e + 3);
-        PROF_MARK(e + 4);
-        hipLaunchKernelGGL(k_shade, dim3(ctx->g_shade), block, 0, st, ctx->S, lp, qc, qn, ctx->hb, ctx->ctl, ctx->fb, ctx->beam.litbits, ctx->beam.pair_slot, ctx->beam.queue_n);
-        PROF_MARK(e + 5);
+        return RT_OK;
+    };
+    auto intersect = [&](int level, hipStream_t s_, RayQ &qc, HitBuf &hb, double *fbx, int side) {
+        lp.level = level;
+        lp.last_level = (level == rec) ? 1 : 0;
+        if (fast) hipLaunchKernelGGL(k_intersect<true>, dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, level == 0 ? d_ids : nullptr);
+        else hipLaunchKernelGGL(k_intersect<false>, dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, level == 0 ? d_ids : nullptr);
+    };
+    auto queue_of = [&](int level) -> RayQ & { return level == 0 ? ctx->q[0] : ctx->q[1 + ((level - 1) & 1)]; };
+
+    if (!overlap) {
+        for (int level = 0; level <= rec; ++level) {
+            RayQ &qc = queue_of(level), &qn = queue_of(level + 1);
+            HitBuf &hb = level == 0 ? ctx->hb : ctx->hb1;
+            BeamBuf &bb = level == 0 ? ctx->beam : ctx->beam1;
+            const int e = 2 + 6 * level;
+            PROF_MARK(e + 0);
+            intersect(level, st, qc, hb, level == 0 ? fb0 : ctx->fb, 0);
+            PROF_MARK(e + 1);
+            PROF_MARK(e + 2);
+            if (int rc = shadows(level, st, qc, hb, level == 0 ? ctx->seg : ctx->seg1, bb, 0)) return rc;
+            PROF_MARK(e + 3);
+            PROF_MARK(e + 4);
+            if (level == 0) {
+                hipLaunchKernelGGL(k_shade<RT_SHADE_LIGHTS>, dim3(ctx->g_shade), block, 0, st, ctx->S, lp, qc, qn, hb, ctx->ctl, fb0, bb.litbits, bb.pair_slot, bb.queue_n);
+                hipLaunchKernelGGL(k_shade<RT_SHADE_SPAWN>, dim3(ctx->g_shade), block, 0, st, ctx->S, lp, qc, qn, hb, ctx->ctl, ctx->fb, bb.litbits, bb.pair_slot, bb.queue_n);
+            } else
+                hipLaunchKernelGGL(k_shade<3>, dim3(ctx->g_shade), block, 0, st, ctx->S, lp, qc, qn, hb, ctx->ctl, ctx->fb, bb.litbits, bb.pair_slot, bb.queue_n);
+            PROF_MARK(e + 5);
+        }
+    } else {
+        hipStream_t s2_ = ctx->stream2;
+        intersect(0, st, ctx->q[0], ctx->hb, fb0, 0);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
+        HIP_TRY(ctx, hipStreamWaitEvent(s2_, ctx->ev_fork, 0));
+        // deeper levels (stream2)
+        lp.level = 0; lp.last_level = 0;
+        hipLaunchKernelGGL(k_shade<RT_SHADE_SPAWN>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s2_, ctx->S, lp, ctx->q[0], ctx->q[1], ctx->hb, ctx->ctl, ctx->fb,
+                           ctx->beam.litbits, ctx->beam.pair_slot, ctx->beam.queue_n);
+        for (int level = 1; level <= rec; ++level) {
+            RayQ &qc = queue_of(level), &qn = queue_of(level + 1);
+            intersect(level, s2_, qc, ctx->hb1, ctx->fb, 2);
+            if (int rc = shadows(level, s2_, qc, ctx->hb1, ctx->seg1, ctx->beam1, 2)) return rc;
+            hipLaunchKernelGGL(k_shade<3>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s2_, ctx->S, lp, qc, qn, ctx->hb1, ctx->ctl, ctx->fb,
+                               ctx->beam1.litbits, ctx->beam1.pair_slot, ctx->beam1.queue_n);
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_join, s2_));
+        // level 0 (caller's stream)
+        if (int rc = shadows(0, st, ctx->q[0], ctx->hb, ctx->seg, ctx->beam, 1)) return rc;
+        hipLaunchKernelGGL(k_shade<RT_SHADE_LIGHTS>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 1)), block, 0, st, ctx->S, lp, ctx->q[0], ctx->q[1], ctx->hb, ctx->ctl, fb0,
+                           ctx->beam.litbits, ctx->beam.pair_slot, ctx->beam.queue_n);
+        HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
     }
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
@@ -1608,6 +1691,7 @@ extern "C" int rt_render_device(rt_ctx *ctx, const rt_render_params *p, float *d
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
     HIP_TRY(ctx, hipMemsetAsync(ctx->ctl, 0, sizeof(FrameCtl), st));
     HIP_TRY(ctx, hipMemsetAsync(ctx->fb, 0, g.out_slots * 3 * sizeof(double), st));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->fb0, 0, g.out_slots * 3 * sizeof(double), st));
     if (d_ids) HIP_TRY(ctx, hipMemsetAsync(d_ids, 0, g.out_slots * sizeof(int32_t), st));
     dim3 grid(ctx->grid), block(RT_BLOCK);
     if (rec < 0) {
@@ -1620,10 +1704,10 @@ extern "C" int rt_render_device(rt_ctx *ctx, const rt_render_params *p, float *d
         PROF_MARK(0);
         hipLaunchKernelGGL(k_gen, grid, block, 0, st, gp, ctx->q[0], ctx->ctl);
         PROF_MARK(1);
-        if (int rc = enqueue_levels(ctx, p, sh, rec, d_ids, st)) return rc;
+        if (int rc = enqueue_levels(ctx, p, sh, rec, d_ids, st, ctx->fb0)) return rc;
     }
     PROF_MARK(2 + 6 * (rec + 1));
-    if (d_rgb || d_rgb8) hipLaunchKernelGGL(k_resolve, grid, block, 0, st, ctx->fb, g.out_slots * 3, d_rgb, d_rgb8);
+    if (d_rgb || d_rgb8) hipLaunchKernelGGL(k_resolve, grid, block, 0, st, ctx->fb, ctx->fb0, g.out_slots * 3, d_rgb, d_rgb8);
     PROF_MARK(3 + 6 * (rec + 1));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctl, ctx->ctl, sizeof(FrameCtl), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
@@ -1780,7 +1864,7 @@ extern "C" int rt_trace(rt_ctx *ctx, const rt_render_params *p, const double *or
             rt_render_params pp = *p;
             pp.flags &= ~RT_FLAG_PROFILE;
             ctx->prof_levels = -1;
-            rc = enqueue_levels(ctx, &pp, sh, rec, nullptr, st);
+            rc = enqueue_levels(ctx, &pp, sh, rec, nullptr, st, ctx->fb);   // one framebuffer: rgb_out is its raw float64 content
             if (rc != RT_OK) break;
         }
         TRY_T(hipMemcpyAsync(ctx->h_ctl, ctx->ctl, sizeof(FrameCtl), hipMemcpyDeviceToHost, st));

@@ -295,3 +295,17 @@ def test_beam_path_frame_matches_oracle_on_stress_scene(oracle):
     assert np.array_equal(out["ids"], ref["ids"])
     assert np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
     assert out["stats"]["shadow_rays"] == ref["counters"]["shadow_rays"]
+
+
+@pytest.mark.parametrize("tag,w,h,sh,rec", [("synth400", 320, 180, 5, 5), ("pool", 320, 180, 3, 10), ("small", 160, 100, 2, 4)])
+def test_overlapped_levels_equal_sequential_levels(gpu_ctx, tag, w, h, sh, rec):
+    """The default schedule runs levels 1.. beside the soft shadows of level 0 (second stream, second buffer set);
+    RT_FLAG_NO_OVERLAP runs the levels one after the other.  Same frame, same counters, several frames in a row."""
+    ctx = gpu_ctx(tag)
+    for seed in (1, 2, 3):
+        seq = ctx.render(abi.render_params(w, h, sh_rays=sh, rec_max=rec, jitter=True, seed=seed, flags=abi.RT_FLAG_NO_OVERLAP))
+        ovl = ctx.render(abi.render_params(w, h, sh_rays=sh, rec_max=rec, jitter=True, seed=seed))
+        assert np.array_equal(ovl["ids"], seq["ids"])
+        assert np.array_equal(ovl["rgb"], seq["rgb"])
+        for key in ("rays", "shadow_rays", "reflect_rays", "transmit_rays", "hits"):
+            assert ovl["stats"][key] == seq["stats"][key], key
