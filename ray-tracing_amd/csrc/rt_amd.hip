@@ -85,6 +85,7 @@ struct LevelParams {
     // beam path: a chunk of RT_BLOCK lanes holds spb whole (hit, light) pairs of s2 rays each
     uint32_t spb, magic_s2, magic_s;     // magic_x = ceil(2^32 / x): n / x == __umulhi(n, magic_x) for n < 2^16
     int32_t beam;                        // this frame's soft shadows go through the beam path
+    int32_t prio;                        // overlapped frame, deeper levels: raise the waves' issue priority
 };
 
 // XCD-aware chunk walk.  A chunk is RT_BLOCK consecutive items; chunks are dealt to the 8 XCDs in groups of
@@ -254,7 +255,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_intersect(DScene S, FastScene F, L
                                                         FrameCtl *ctl, double *fb, int32_t *ids_out) {
     extern __shared__ uint2 lds_stack[];
     uint2 *stk = lds_stack + threadIdx.x;
-    if (ctl->overflow) return;   // a queue overflowed earlier in this frame: the frame is void
+    if (ctl->overflow) return;
+    if (lp.prio) __builtin_amdgcn_s_setprio(3);   // a queue overflowed earlier in this frame: the frame is void
     const uint32_t n = min(ctl->n_rays[lp.level], lp.cap);
     ChunkWalk walk(n);
     uint64_t first;
@@ -307,6 +309,7 @@ __device__ __forceinline__ void exact_basis(const DLight &Lt, int sh_rays, d3 P,
 // NO_BEAM / exact modes: the float64 basis once per (hit, shadow light); k_shadow's s*s lanes of a pair reuse it
 __global__ void __launch_bounds__(RT_BLOCK) k_shadow_setup(DScene S, LevelParams lp, HitBuf hb, SegBuf sg, FrameCtl *ctl) {
     if (ctl->overflow) return;
+    if (lp.prio) __builtin_amdgcn_s_setprio(3);
     const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
     const uint32_t nsl = (uint32_t)S.n_shadow_lights;
     const uint64_t total = (uint64_t)n_hits * nsl;
@@ -340,6 +343,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
     __shared__ uint32_t lbuf_all[(RT_BLOCK / 64) * 128];
     __shared__ uint32_t tl_all[RT_TOUCH * RT_BLOCK];     // [entry][lane]: touched leaf entries of the lane's traversal
     if (ctl->overflow) return;
+    if (lp.prio) __builtin_amdgcn_s_setprio(3);
     const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
     const uint32_t nsl = (uint32_t)S.n_shadow_lights;
     const uint32_t total = n_hits * nsl;           // < 2^32: checked on the host
@@ -557,6 +561,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene S, FastScene F, Leve
     extern __shared__ uint2 lds_stack[];
     uint2 *stk = lds_stack + threadIdx.x;
     if (ctl->overflow) return;
+    if (lp.prio) __builtin_amdgcn_s_setprio(3);
     const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
     const uint32_t s2 = (uint32_t)(lp.sh_rays * lp.sh_rays);
     const uint64_t total = (uint64_t)n_hits * (uint32_t)S.n_shadow_lights * s2;
@@ -585,6 +590,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
     __shared__ float4 pair_lds_all[(RT_BLOCK / 64) * RT_WAVE_UNITS];
     __shared__ unsigned long long qbuf_all[(RT_BLOCK / 64) * 128];
     if (ctl->overflow) return;
+    if (lp.prio) __builtin_amdgcn_s_setprio(3);
     const uint32_t NONE = 0xffffffffu;
     const uint32_t s = (uint32_t)lp.sh_rays, s2 = s * s;
     const uint32_t queue_cap = bb.queue_n[2];
@@ -779,6 +785,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_queue(DScene S, FastScene F
     extern __shared__ uint2 lds_stack[];
     uint2 *stk = lds_stack + threadIdx.x;
     if (ctl->overflow) return;
+    if (lp.prio) __builtin_amdgcn_s_setprio(3);
     const uint32_t n = min(bb.queue_n[0], bb.queue_n[2]);
     const uint32_t s2 = (uint32_t)(lp.sh_rays * lp.sh_rays);
     ChunkWalk walk(n);
@@ -800,6 +807,7 @@ template <int MODE>
 __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, LevelParams lp, RayQ q, RayQ qn, HitBuf hb, FrameCtl *ctl,
                                                     double *fb, const unsigned long long *litbits, const uint32_t *pair_slot, const uint32_t *queue_n) {
     if (ctl->overflow) return;
+    if (lp.prio) __builtin_amdgcn_s_setprio(3);
     if ((MODE & RT_SHADE_LIGHTS) && lp.beam && blockIdx.x == 0 && threadIdx.x == 0) { ctl->n_queued[lp.level] = queue_n[0]; ctl->n_listed[lp.level] = queue_n[1]; }
     const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
     const uint32_t nsl = (uint32_t)S.n_shadow_lights;
@@ -1168,6 +1176,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
     HIP_C(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIP_C(hipEventCreate(&ctx->ev0));
     HIP_C(hipEventCreate(&ctx->ev1));
+    // (a high-priority stream here hung the GPU under the persistent level-0 kernels; wave priority is set in the kernels instead)
     HIP_C(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
     HIP_C(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     HIP_C(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
@@ -1635,7 +1644,13 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         intersect(0, st, ctx->q[0], ctx->hb, fb0, 0);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
         HIP_TRY(ctx, hipStreamWaitEvent(s2_, ctx->ev_fork, 0));
-        // deeper levels (stream2)
+        // level 0 (caller's stream) is submitted first: the host needs ~10 us per launch, and the long chain of the
+        // deeper levels must not delay the submission of the frame's largest kernel
+        if (int rc = shadows(0, st, ctx->q[0], ctx->hb, ctx->seg, ctx->beam, 1)) return rc;
+        hipLaunchKernelGGL(k_shade<RT_SHADE_LIGHTS>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 1)), block, 0, st, ctx->S, lp, ctx->q[0], ctx->q[1], ctx->hb, ctx->ctl, fb0,
+                           ctx->beam.litbits, ctx->beam.pair_slot, ctx->beam.queue_n);
+        // deeper levels (stream2): few, long rays - their waves ask for issue priority over the level-0 waves
+        lp.prio = getenv("RT_AMD_NO_PRIO") ? 0 : 1;
         lp.level = 0; lp.last_level = 0;
         hipLaunchKernelGGL(k_shade<RT_SHADE_SPAWN>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s2_, ctx->S, lp, ctx->q[0], ctx->q[1], ctx->hb, ctx->ctl, ctx->fb,
                            ctx->beam.litbits, ctx->beam.pair_slot, ctx->beam.queue_n);
@@ -1646,11 +1661,8 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
             hipLaunchKernelGGL(k_shade<3>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s2_, ctx->S, lp, qc, qn, ctx->hb1, ctx->ctl, ctx->fb,
                                ctx->beam1.litbits, ctx->beam1.pair_slot, ctx->beam1.queue_n);
         }
+        lp.prio = 0;
         HIP_TRY(ctx, hipEventRecord(ctx->ev_join, s2_));
-        // level 0 (caller's stream)
-        if (int rc = shadows(0, st, ctx->q[0], ctx->hb, ctx->seg, ctx->beam, 1)) return rc;
-        hipLaunchKernelGGL(k_shade<RT_SHADE_LIGHTS>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 1)), block, 0, st, ctx->S, lp, ctx->q[0], ctx->q[1], ctx->hb, ctx->ctl, fb0,
-                           ctx->beam.litbits, ctx->beam.pair_slot, ctx->beam.queue_n);
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
     }
     HIP_TRY(ctx, hipGetLastError());

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--rec-max", type=int, default=None)
     ap.add_argument("--no-jitter", action="store_true")
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernel families with events (keeps the overlapped schedule)")
     a = ap.parse_args()
     import bench
     from ray_tracing_amd import abi, native
@@ -27,7 +28,7 @@ def main():
     with native.Context(scene.packed) as ctx:
         for k in range(a.frames):
             out = ctx.render(abi.render_params(a.width, a.height, sh_rays=a.sh_rays, rec_max=a.rec_max,
-                                               jitter=not a.no_jitter, seed=k, flags=a.flags | abi.RT_FLAG_PROFILE),
+                                               jitter=not a.no_jitter, seed=k, flags=a.flags | (0 if a.no_profile else abi.RT_FLAG_PROFILE)),
                              want_rgb=False, want_ids=False)
         st = out["stats"]
         print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()})
