@@ -329,6 +329,44 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_setup(DScene S, LevelParams
     }
 }
 
+// Wave-private append: values are parked in the wave's LDS buffer (128 entries) and get their slots 64 at a time -
+// ONE returning atomic on the counter per 64 values (returning atomics on a single address complete at ~30 ns
+// each; one per wave and chunk was the bottleneck of the kernels that append).  All 64 lanes call these together.
+template <typename Store>
+__device__ __forceinline__ void wave_append(bool flag, uint32_t value, uint32_t *buf, uint32_t &n, uint32_t *counter, int lane, Store store) {
+    const unsigned long long m = __ballot(flag);
+    if (!m) return;
+    if (flag) buf[n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
+    n += (uint32_t)__popcll(m);
+    if (n >= 64u) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(counter, 64u);
+        base = __shfl(base, 0);
+        const uint32_t v = buf[lane], v2 = buf[64 + lane];
+        store(base + (uint32_t)lane, v);
+        n -= 64u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if ((uint32_t)lane < n) buf[lane] = v2;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+template <typename Store>
+__device__ __forceinline__ void wave_append_flush(uint32_t *buf, uint32_t n, uint32_t *counter, int lane, Store store) {
+    if (!n) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(counter, n);
+    base = __shfl(base, 0);
+    if ((uint32_t)lane < n) store(base + (uint32_t)lane, buf[lane]);
+}
+
 // beam path: one lane per (hit, shadow light) pair (rt_shadow.hpp).  The basis is computed in float32 from the
 // float64 difference light - P; its error is part of the direction-error budget RT_RHO of the per-ray predicates.
 // A pair ends in one of three ways:
@@ -340,7 +378,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_setup(DScene S, LevelParams
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) k_beam_setup(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb, BeamBuf bb,
                                                          FrameCtl *ctl) {
     extern __shared__ uint2 lds_stack[];
-    __shared__ uint32_t lbuf_all[(RT_BLOCK / 64) * 128];
+    __shared__ uint32_t lbuf_all[(RT_BLOCK / 64) * 128], obuf_all[(RT_BLOCK / 64) * 128];
     __shared__ uint32_t tl_all[RT_TOUCH * RT_BLOCK];     // [entry][lane]: touched leaf entries of the lane's traversal
     if (ctl->overflow) return;
     if (lp.prio) __builtin_amdgcn_s_setprio(3);
@@ -350,8 +388,10 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
     const int lane = threadIdx.x & 63;
     // listed pairs are parked in a wave-private LDS buffer and get their slots 64 at a time (one returning
     // atomic on the list counter per 64 pairs; see k_shadow_beam)
-    uint32_t *lbuf = lbuf_all + (threadIdx.x >> 6) * 128;
-    uint32_t ln = 0u;
+    uint32_t *lbuf = lbuf_all + (threadIdx.x >> 6) * 128, *obuf = obuf_all + (threadIdx.x >> 6) * 128;
+    uint32_t ln = 0u, on = 0u;
+    auto store_listed = [&](uint32_t slot, uint32_t pair) { bb.list[slot] = pair; bb.pair_slot[pair] = slot; };
+    auto store_ovf = [&](uint32_t slot, uint32_t pair) { bb.ovlist[slot] = pair; };
     // A wave takes 64 CONSECUTIVE HITS and ONE light: neighbouring hits (neighbouring pixels at level 0) send
     // nearly the same beam through the tree, the lanes of a wave stay on one path.
     const uint32_t hit_blocks = (n_hits + 63u) >> 6;
@@ -364,7 +404,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
         const uint32_t h = (hblk << 6) + (uint32_t)lane;
         const bool valid = hblk < hit_blocks && h < n_hits;
         const uint32_t seg = h * nsl + ml;
-        bool listed = false;
+        bool listed = false, ovf = false;
         if (valid) {
             const uint32_t r = hb.list[h];
             const int m = S.shadow_lights[ml];
@@ -451,49 +491,19 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                 else if (bo.nu == 0 && n_eval == 0) whole = (n_atp + (bo.atp_all ? 1u : 0u)) > 0 ? RT_PAIR_LIT : RT_PAIR_UNLIT;
             }
             if (whole) bb.pair_slot[seg] = whole;
-            else {
+            else if (bo.overflow) {                         // all its rays go to the float64 kernel, which expands the pair itself
+                ovf = true;
+                bb.pair_slot[seg] = RT_PAIR_UNLIT;          // nothing from the filter: the lit count is the queue kernel's alone
+            } else {
                 listed = true;
-                const uint32_t nc = bo.overflow ? RT_META_OVERFLOW : (bo.nu | (bo.boxmask << 8));
-                reinterpret_cast<uint32_t *>(rec + 1)[3] = nc | ((uint32_t)m << 16) | (pcls << 24) | (bo.atp_all ? 1u << 30 : 0u);
+                reinterpret_cast<uint32_t *>(rec + 1)[3] = bo.nu | (bo.boxmask << 8) | ((uint32_t)m << 16) | (pcls << 24) | (bo.atp_all ? 1u << 30 : 0u);
             }
         }
-        // listed pairs -> wave buffer -> bb.list
-        const unsigned long long lm = __ballot(listed);
-        if (lm) {
-            if (listed) lbuf[ln + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull))] = seg;
-            ln += (uint32_t)__popcll(lm);
-            if (ln >= 64u) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&bb.queue_n[1], 64u);
-                base = __shfl(base, 0);
-                const uint32_t v = lbuf[lane], v2 = lbuf[64 + lane];
-                bb.list[base + (uint32_t)lane] = v;
-                bb.pair_slot[v] = base + (uint32_t)lane;
-                ln -= 64u;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                if ((uint32_t)lane < ln) lbuf[lane] = v2;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
+        wave_append(listed, seg, lbuf, ln, &bb.queue_n[1], lane, store_listed);
+        wave_append(ovf, seg, obuf, on, &bb.queue_n[2], lane, store_ovf);
     }
-    if (ln) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&bb.queue_n[1], ln);
-        base = __shfl(base, 0);
-        if ((uint32_t)lane < ln) {
-            const uint32_t v = lbuf[lane];
-            bb.list[base + (uint32_t)lane] = v;
-            bb.pair_slot[v] = base + (uint32_t)lane;
-        }
-    }
+    wave_append_flush(lbuf, ln, &bb.queue_n[1], lane, store_listed);
+    wave_append_flush(obuf, on, &bb.queue_n[2], lane, store_ovf);
 }
 
 // float64-confirmed verdict for shadow ray g (rt_fast.hpp), or the reference-order walk when !FAST
@@ -593,7 +603,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
     if (lp.prio) __builtin_amdgcn_s_setprio(3);
     const uint32_t NONE = 0xffffffffu;
     const uint32_t s = (uint32_t)lp.sh_rays, s2 = s * s;
-    const uint32_t queue_cap = bb.queue_n[2];
+    const uint32_t queue_cap = bb.queue_n[3];
     const uint32_t nlist = min(bb.queue_n[1], min(ctl->n_hits[lp.level], lp.cap) * (uint32_t)S.n_shadow_lights);
     const uint32_t nchunks = (nlist + lp.spb - 1) / lp.spb;
     ChunkWalk walk((uint64_t)nchunks * RT_BLOCK);
@@ -786,14 +796,23 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_queue(DScene S, FastScene F
     uint2 *stk = lds_stack + threadIdx.x;
     if (ctl->overflow) return;
     if (lp.prio) __builtin_amdgcn_s_setprio(3);
-    const uint32_t n = min(bb.queue_n[0], bb.queue_n[2]);
+    // work = the rays the filter queued, then every ray of the pairs that never reached the filter (candidate
+    // overflow, delicate basis): those are expanded here, s*s consecutive items per pair
+    const uint32_t n = min(bb.queue_n[0], bb.queue_n[3]);
     const uint32_t s2 = (uint32_t)(lp.sh_rays * lp.sh_rays);
-    ChunkWalk walk(n);
+    const uint64_t total = (uint64_t)n + (uint64_t)bb.queue_n[2] * s2;
+    ChunkWalk walk(total);
     uint64_t first;
     while (walk.next(first)) {
         uint64_t i = first + threadIdx.x;
-        if (i >= n) continue;
-        const uint64_t g = bb.queue[i];
+        if (i >= total) continue;
+        uint64_t g;
+        if (i < n) g = bb.queue[i];
+        else {
+            const uint64_t j = i - n;
+            const uint32_t pi = (uint32_t)(j / s2);
+            g = (uint64_t)bb.ovlist[pi] * s2 + (j - (uint64_t)pi * s2);
+        }
         if (shadow_ray_lit<true, false>(S, F, stk, lp, q, hb, sg, g)) atomicAdd(&hb.lit[g / s2], 1u);
     }
 }
@@ -808,7 +827,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, LevelParams lp, Ra
                                                     double *fb, const unsigned long long *litbits, const uint32_t *pair_slot, const uint32_t *queue_n) {
     if (ctl->overflow) return;
     if (lp.prio) __builtin_amdgcn_s_setprio(3);
-    if ((MODE & RT_SHADE_LIGHTS) && lp.beam && blockIdx.x == 0 && threadIdx.x == 0) { ctl->n_queued[lp.level] = queue_n[0]; ctl->n_listed[lp.level] = queue_n[1]; }
+    if ((MODE & RT_SHADE_LIGHTS) && lp.beam && blockIdx.x == 0 && threadIdx.x == 0) { ctl->n_queued[lp.level] = queue_n[0] + queue_n[2] * (uint32_t)(lp.sh_rays * lp.sh_rays); ctl->n_listed[lp.level] = queue_n[1]; }
     const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
     const uint32_t nsl = (uint32_t)S.n_shadow_lights;
     const double s2 = (double)(lp.sh_rays * lp.sh_rays);
@@ -1063,6 +1082,7 @@ struct rt_ctx {
     SegBuf seg1{};
     BeamBuf beam1{};
     double *fb = nullptr, *fb0 = nullptr;   // see k_resolve
+    bool two_sets = false;                  // hb1 / seg1 / beam1 are separate allocations
     hipStream_t stream2 = nullptr;          // the deeper levels of an overlapped frame
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int nb_intersect = 1, nb_beam_setup = 1, nb_beam = 1, nb_queue = 1, nb_shade = 1, nb_setup = 1, nb_shadow = 1;   // workgroups per CU
@@ -1459,7 +1479,18 @@ static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
     }
     uint64_t nlit = cap * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1);
     ctx->beam_queue_cap = (uint32_t)(cap < 0x7fffffffull ? cap : 0x7fffffffull);
+    ctx->two_sets = true;
     for (int set = 0; set < 2; ++set) {          // level 0 / deeper levels: the two halves of an overlapped frame
+        if (set == 1) {
+            // the second set is a speed-up only: without the memory for it the levels share one set and run in sequence
+            size_t free_b = 0, total_b = 0;
+            const uint64_t need_b = cap * 40 + nlit * (4 + 72 + 16 * RT_PAIR_UNITS + 8 * (RT_BLOCK / 64) + 12) + (uint64_t)ctx->beam_queue_cap * 8;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (uint64_t)free_b < need_b + need_b / 8 + slots * 24 || getenv("RT_AMD_ONE_SET")) {
+                ctx->hb1 = ctx->hb; ctx->seg1 = ctx->seg; ctx->beam1 = ctx->beam;
+                ctx->two_sets = false;
+                break;
+            }
+        }
         HitBuf &hb = set ? ctx->hb1 : ctx->hb;
         TRY_A(dalloc(ctx, &hb.px, cap)); TRY_A(dalloc(ctx, &hb.py, cap)); TRY_A(dalloc(ctx, &hb.pz, cap));
         TRY_A(dalloc(ctx, &hb.id, cap)); TRY_A(dalloc(ctx, &hb.list, cap));
@@ -1473,8 +1504,8 @@ static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
         TRY_A(dalloc(ctx, &bb.rec, (nlit + RT_BLOCK) * RT_PAIR_UNITS));   // + one chunk of slack: staging reads whole chunks
         TRY_A(dalloc(ctx, &bb.queue, (uint64_t)ctx->beam_queue_cap)); TRY_A(dalloc(ctx, &bb.queue_n, 4));
         TRY_A(dalloc(ctx, &bb.litbits, (nlit + 1) * (RT_BLOCK / 64)));      // worst case one pair per chunk (s*s > RT_BLOCK / 2)
-        TRY_A(dalloc(ctx, &bb.list, nlit)); TRY_A(dalloc(ctx, &bb.pair_slot, nlit));
-        uint32_t init[4] = {0u, 0u, ctx->beam_queue_cap, 0u};
+        TRY_A(dalloc(ctx, &bb.list, nlit)); TRY_A(dalloc(ctx, &bb.pair_slot, nlit)); TRY_A(dalloc(ctx, &bb.ovlist, nlit));
+        uint32_t init[4] = {0u, 0u, 0u, ctx->beam_queue_cap};
         HIP_TRY(ctx, hipMemcpy(bb.queue_n, init, sizeof(init), hipMemcpyHostToDevice));
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1584,7 +1615,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         lp.magic_s2 = (uint32_t)((0x100000000ull + s2 - 1) / s2);
         lp.magic_s = (uint32_t)((0x100000000ull + (uint32_t)sh - 1) / (uint32_t)sh);
     }
-    const bool overlap = fast && !prof && rec >= 1 && fb0 != ctx->fb && !(p->flags & RT_FLAG_NO_OVERLAP) && ctx->n_cu >= 8;
+    const bool overlap = fast && !prof && rec >= 1 && fb0 != ctx->fb && ctx->two_sets && !(p->flags & RT_FLAG_NO_OVERLAP) && ctx->n_cu >= 8;
     static const int ovl_main = getenv("RT_AMD_OVL_MAIN") ? atoi(getenv("RT_AMD_OVL_MAIN")) : 3;   // workgroups per CU, level-0 side
     static const int ovl_side = getenv("RT_AMD_OVL_SIDE") ? atoi(getenv("RT_AMD_OVL_SIDE")) : 1;   // deeper levels
     // grid of a kernel with nb workgroups per CU at full occupancy: side 0 = sequential, 1 = level-0 side, 2 = deeper levels
@@ -1600,7 +1631,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         lp.last_level = (level == rec) ? 1 : 0;
         if (ctx->S.n_shadow_lights <= 0) return RT_OK;
         if (beam) {
-            HIP_TRY(ctx, hipMemsetAsync(bb.queue_n, 0, 2 * sizeof(uint32_t), s_));
+            HIP_TRY(ctx, hipMemsetAsync(bb.queue_n, 0, 3 * sizeof(uint32_t), s_));
             hipLaunchKernelGGL(k_beam_setup, dim3(gsz(ctx->g_beam_setup, ctx->nb_beam_setup, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
             hipLaunchKernelGGL(k_shadow_beam, dim3(gsz(ctx->g_beam, ctx->nb_beam, side)), block, 0, s_, ctx->S, lp, hb, bb, ctx->ctl);
             hipLaunchKernelGGL(k_shadow_queue, dim3(gsz(ctx->g_queue, ctx->nb_queue, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, sg, bb, ctx->ctl);

@@ -45,7 +45,8 @@ struct CandF {               // decoded candidate
 struct BeamBuf {
     float4 *rec;             // [pair][RT_PAIR_UNITS]
     unsigned long long *queue;   // shadow-ray numbers g the filter could not decide
-    uint32_t *queue_n;       // [0] = queue entries appended, [1] = pairs listed, [2] = queue capacity
+    uint32_t *queue_n;       // [0] = queue entries appended, [1] = pairs listed, [2] = pairs in ovlist, [3] = queue capacity
+    uint32_t *ovlist;        // pairs whose rays all go to the float64 kernel (candidate overflow, delicate basis)
     uint32_t *list;          // [slot] -> pair: the pairs whose rays need the per-ray filter, in no particular order
     uint32_t *pair_slot;     // [pair] -> slot, or RT_PAIR_LIT / RT_PAIR_UNLIT when the whole pair is decided
     unsigned long long *litbits; // [chunk of slots][wave]: which lanes' rays the filter found lit (every word written per level)
