@@ -194,6 +194,35 @@ __device__ __forceinline__ Hit nearest_hit(const DScene &S, const FastScene &F, 
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
+// camera ray of queue item k (ray_functions.py:31-41), written to the queue; false for a padding lane
+__device__ __forceinline__ bool gen_ray(const GenParams &g, const RayQ &q, uint64_t k, d3 &o, d3 &dn, uint32_t &slot) {
+    uint32_t tile_local = (uint32_t)(k / (uint32_t)(g.tw * g.th));
+    uint32_t lane = (uint32_t)(k % (uint32_t)(g.tw * g.th));
+    uint32_t tile = g.world > 1 ? (uint32_t)g.rank + tile_local * (uint32_t)g.world : tile_local;
+    int x = (int)(tile % (uint32_t)g.tiles_x) * g.tw + (int)(lane % (uint32_t)g.tw);
+    int y = (int)(tile / (uint32_t)g.tiles_x) * g.th + (int)(lane / (uint32_t)g.tw);
+    bool valid = tile < (uint32_t)g.n_tiles && x < g.W && y < g.H;
+    if (!valid) {
+        q.slot[k] = RT_INVALID_SLOT;
+        slot = RT_INVALID_SLOT;
+        return false;
+    }
+    d3 pos = ld3(g.pos), X = ld3(g.X), Y = ld3(g.Y), p00 = ld3(g.p00);
+    d3 dest = (p00 - ((double)y * g.hg) * Y) + ((double)x * g.wg) * X;
+    d3 dir = dest - pos;
+    dn = dir / norm3(dir);
+    o = pos;
+    q.ox[k] = pos.x; q.oy[k] = pos.y; q.oz[k] = pos.z;
+    q.dx[k] = dn.x; q.dy[k] = dn.y; q.dz[k] = dn.z;
+    q.tr[k] = 1.0; q.tg[k] = 1.0; q.tb[k] = 1.0;
+    uint32_t gp = (uint32_t)y * (uint32_t)g.W + (uint32_t)x;
+    slot = g.world > 1 ? (uint32_t)k : gp;
+    q.slot[k] = slot;
+    q.gpix[k] = gp;
+    q.path[k] = 1u;
+    return true;
+}
+
 __global__ void __launch_bounds__(RT_BLOCK) k_gen(GenParams g, RayQ q, FrameCtl *ctl) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ctl->n_rays[0] = g.n_slots;
@@ -204,29 +233,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_gen(GenParams g, RayQ q, FrameCtl 
     while (walk.next(first)) {
         uint64_t k = first + threadIdx.x;
         if (k >= g.n_slots) continue;
-        uint32_t tile_local = (uint32_t)(k / (uint32_t)(g.tw * g.th));
-        uint32_t lane = (uint32_t)(k % (uint32_t)(g.tw * g.th));
-        uint32_t tile = g.world > 1 ? (uint32_t)g.rank + tile_local * (uint32_t)g.world : tile_local;
-        int x = (int)(tile % (uint32_t)g.tiles_x) * g.tw + (int)(lane % (uint32_t)g.tw);
-        int y = (int)(tile / (uint32_t)g.tiles_x) * g.th + (int)(lane / (uint32_t)g.tw);
-        bool valid = tile < (uint32_t)g.n_tiles && x < g.W && y < g.H;
-        if (!valid) {
-            q.slot[k] = RT_INVALID_SLOT;
-            continue;
-        }
-        // ray_functions.py:31-41
-        d3 pos = ld3(g.pos), X = ld3(g.X), Y = ld3(g.Y), p00 = ld3(g.p00);
-        d3 dest = (p00 - ((double)y * g.hg) * Y) + ((double)x * g.wg) * X;
-        d3 dir = dest - pos;
-        d3 dn = dir / norm3(dir);
-        q.ox[k] = pos.x; q.oy[k] = pos.y; q.oz[k] = pos.z;
-        q.dx[k] = dn.x; q.dy[k] = dn.y; q.dz[k] = dn.z;
-        q.tr[k] = 1.0; q.tg[k] = 1.0; q.tb[k] = 1.0;
-        uint32_t gp = (uint32_t)y * (uint32_t)g.W + (uint32_t)x;
-        q.slot[k] = g.world > 1 ? (uint32_t)k : gp;
-        q.gpix[k] = gp;
-        q.path[k] = 1u;
-        valid_total++;
+        d3 o, dn;
+        uint32_t slot;
+        if (gen_ray(g, q, k, o, dn, slot)) valid_total++;
     }
     // primary-ray count (padding lanes excluded)
     for (int off = 32; off > 0; off >>= 1) valid_total += __shfl_down(valid_total, off);
@@ -250,31 +259,44 @@ __global__ void __launch_bounds__(RT_BLOCK) k_load_rays(const double *o, const d
     }
 }
 
-template <bool FAST>
-__global__ void __launch_bounds__(RT_BLOCK) k_intersect(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb,
-                                                        FrameCtl *ctl, double *fb, int32_t *ids_out) {
+// GEN (level 0 of a frame): the camera rays are made here and written to the queue on the way - their stores
+// overlap the traversal instead of costing a launch of their own (k_gen) before it.
+template <bool FAST, bool GEN>
+__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) k_intersect(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb,
+                                                        FrameCtl *ctl, double *fb, int32_t *ids_out, GenParams gp) {
     extern __shared__ uint2 lds_stack[];
     uint2 *stk = lds_stack + threadIdx.x;
-    if (ctl->overflow) return;
-    if (lp.prio) __builtin_amdgcn_s_setprio(3);   // a queue overflowed earlier in this frame: the frame is void
-    const uint32_t n = min(ctl->n_rays[lp.level], lp.cap);
+    if (ctl->overflow) return;                    // a queue overflowed earlier in this frame: the frame is void
+    if (lp.prio) __builtin_amdgcn_s_setprio(3);
+    const uint32_t n = GEN ? gp.n_slots : min(ctl->n_rays[lp.level], lp.cap);
+    if (GEN && blockIdx.x == 0 && threadIdx.x == 0) ctl->n_rays[0] = gp.n_slots;
     ChunkWalk walk(n);
     uint64_t first;
     const int lane = threadIdx.x & 63;
+    unsigned long long valid_total = 0;
     while (walk.next(first)) {
         uint64_t k = first + threadIdx.x;
         bool active = k < n;
-        uint32_t slot = active ? q.slot[k] : RT_INVALID_SLOT;
-        active = active && slot != RT_INVALID_SLOT;
+        uint32_t slot = RT_INVALID_SLOT;
+        d3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
+        if (GEN) {
+            if (active) active = gen_ray(gp, q, k, o, d, slot);
+            valid_total += active ? 1ull : 0ull;
+        } else {
+            slot = active ? q.slot[k] : RT_INVALID_SLOT;
+            active = active && slot != RT_INVALID_SLOT;
+            if (active) {
+                o = mk3(q.ox[k], q.oy[k], q.oz[k]);
+                d = mk3(q.dx[k], q.dy[k], q.dz[k]);
+            }
+        }
         bool has_hit = false;
         if (active) {
-            d3 o = mk3(q.ox[k], q.oy[k], q.oz[k]);
-            d3 d = mk3(q.dx[k], q.dy[k], q.dz[k]);
             Hit h = nearest_hit<FAST>(S, F, stk, o, d);
             if (ids_out && lp.level == 0) ids_out[slot] = h.id;
             if (h.id == 0) {
                 // ray_tracer.py:65,72,132: misses keep the background colour
-                d3 thr = mk3(q.tr[k], q.tg[k], q.tb[k]);
+                d3 thr = GEN ? mk3(1.0, 1.0, 1.0) : mk3(q.tr[k], q.tg[k], q.tb[k]);
                 fb_add(fb, slot, thr * ld3(S.bg));
             } else {
                 hb.px[k] = h.p.x; hb.py[k] = h.p.y; hb.pz[k] = h.p.z;
@@ -291,6 +313,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_intersect(DScene S, FastScene F, L
             base = __shfl(base, leader);
             if (has_hit) hb.list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)k;
         }
+    }
+    if (GEN) {                                    // primary-ray count (padding lanes excluded)
+        for (int off = 32; off > 0; off >>= 1) valid_total += __shfl_down(valid_total, off);
+        if (lane == 0 && valid_total) atomicAdd(&ctl->primary_rays, valid_total);
     }
 }
 
@@ -1336,7 +1362,8 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
         if (ok) {
             // per-lane stacks can exceed the default 64 KB dynamic-LDS limit on deep trees
             const int big = 160 * 1024;
-            HIP_C(hipFuncSetAttribute((const void *)&k_intersect<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+            HIP_C(hipFuncSetAttribute((const void *)&k_intersect<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+            HIP_C(hipFuncSetAttribute((const void *)&k_intersect<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow_queue, hipFuncAttributeMaxDynamicSharedMemorySize, big));
             HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));   // 14 KB of static LDS (list buffer, touched entries)
@@ -1360,8 +1387,8 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
             return (g + 7) & ~7;
         };
         const size_t lds = ctx->lds_bytes;
-        ctx->g_intersect = grid_for((const void *)&k_intersect<true>, lds); ctx->nb_intersect = last_nb;
-        ctx->g_intersect_x = grid_for((const void *)&k_intersect<false>, 0);
+        ctx->g_intersect = grid_for((const void *)&k_intersect<true, false>, lds); ctx->nb_intersect = last_nb;
+        ctx->g_intersect_x = grid_for((const void *)&k_intersect<false, false>, 0);
         ctx->g_shadow = grid_for((const void *)&k_shadow<true>, lds); ctx->nb_shadow = last_nb;
         ctx->g_shadow_x = grid_for((const void *)&k_shadow<false>, 0);
         ctx->g_beam_setup = grid_for((const void *)&k_beam_setup, lds); ctx->nb_beam_setup = last_nb;
@@ -1598,8 +1625,9 @@ static int prof_prepare(rt_ctx *ctx, int levels) {
 //     stream2 : children of level 0 -> levels 1..rec complete (fb)                     [hb1, seg1, beam1, q[1], q[2]]
 // and joins before the resolve.  Both sides use fixed grids; the level-0 side leaves one workgroup slot per CU to
 // the other.  Results do not depend on the schedule: the two sides add into different framebuffers.
+// gen != nullptr: queue 0 is empty, k_intersect(0) makes the camera rays itself
 static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, int32_t rec, int32_t *d_ids, hipStream_t st,
-                          double *fb0) {
+                          double *fb0, const GenParams *gen) {
     LevelParams lp{};
     lp.sh_rays = sh; lp.jitter = p->jitter; lp.seed = p->seed; lp.cap = (uint32_t)ctx->cap; lp.flags = p->flags;
     dim3 block(RT_BLOCK);
@@ -1645,8 +1673,13 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
     auto intersect = [&](int level, hipStream_t s_, RayQ &qc, HitBuf &hb, double *fbx, int side) {
         lp.level = level;
         lp.last_level = (level == rec) ? 1 : 0;
-        if (fast) hipLaunchKernelGGL(k_intersect<true>, dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, level == 0 ? d_ids : nullptr);
-        else hipLaunchKernelGGL(k_intersect<false>, dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, level == 0 ? d_ids : nullptr);
+        static const GenParams none{};
+        int32_t *ids = level == 0 ? d_ids : nullptr;
+        if (level == 0 && gen) {
+            if (fast) hipLaunchKernelGGL((k_intersect<true, true>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, *gen);
+            else hipLaunchKernelGGL((k_intersect<false, true>), dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, *gen);
+        } else if (fast) hipLaunchKernelGGL((k_intersect<true, false>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, none);
+        else hipLaunchKernelGGL((k_intersect<false, false>), dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, none);
     };
     auto queue_of = [&](int level) -> RayQ & { return level == 0 ? ctx->q[0] : ctx->q[1 + ((level - 1) & 1)]; };
 
@@ -1744,10 +1777,11 @@ extern "C" int rt_render_device(rt_ctx *ctx, const rt_render_params *p, float *d
         HIP_TRY(ctx, hipMemcpyAsync(ctx->fb, bgfill.data(), bgfill.size() * sizeof(double), hipMemcpyHostToDevice, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
     } else {
+        // camera rays: inside k_intersect(0); as a launch of their own only when the kernel families are timed
         PROF_MARK(0);
-        hipLaunchKernelGGL(k_gen, grid, block, 0, st, gp, ctx->q[0], ctx->ctl);
+        if (prof) hipLaunchKernelGGL(k_gen, grid, block, 0, st, gp, ctx->q[0], ctx->ctl);
         PROF_MARK(1);
-        if (int rc = enqueue_levels(ctx, p, sh, rec, d_ids, st, ctx->fb0)) return rc;
+        if (int rc = enqueue_levels(ctx, p, sh, rec, d_ids, st, ctx->fb0, prof ? nullptr : &gp)) return rc;
     }
     PROF_MARK(2 + 6 * (rec + 1));
     if (d_rgb || d_rgb8) hipLaunchKernelGGL(k_resolve, grid, block, 0, st, ctx->fb, ctx->fb0, g.out_slots * 3, d_rgb, d_rgb8);
@@ -1907,7 +1941,7 @@ extern "C" int rt_trace(rt_ctx *ctx, const rt_render_params *p, const double *or
             rt_render_params pp = *p;
             pp.flags &= ~RT_FLAG_PROFILE;
             ctx->prof_levels = -1;
-            rc = enqueue_levels(ctx, &pp, sh, rec, nullptr, st, ctx->fb);   // one framebuffer: rgb_out is its raw float64 content
+            rc = enqueue_levels(ctx, &pp, sh, rec, nullptr, st, ctx->fb, nullptr);   // one framebuffer: rgb_out is its raw float64 content
             if (rc != RT_OK) break;
         }
         TRY_T(hipMemcpyAsync(ctx->h_ctl, ctx->ctl, sizeof(FrameCtl), hipMemcpyDeviceToHost, st));
