@@ -263,10 +263,12 @@ __global__ void __launch_bounds__(RT_BLOCK) k_load_rays(const double *o, const d
 // overlap the traversal instead of costing a launch of their own (k_gen) before it.
 template <bool FAST, bool GEN>
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) k_intersect(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb,
-                                                        FrameCtl *ctl, double *fb, int32_t *ids_out, GenParams gp) {
+                                                        FrameCtl *ctl, double *fb, int32_t *ids_out, GenParams gp, uint32_t *beam_counters) {
     extern __shared__ uint2 lds_stack[];
     uint2 *stk = lds_stack + threadIdx.x;
     if (ctl->overflow) return;                    // a queue overflowed earlier in this frame: the frame is void
+    // the level's soft-shadow kernels follow on this stream: their append counters start at zero (saves a memset launch)
+    if (beam_counters && blockIdx.x == 0 && threadIdx.x < 3) beam_counters[threadIdx.x] = 0u;
     if (lp.prio) __builtin_amdgcn_s_setprio(3);
     const uint32_t n = GEN ? gp.n_slots : min(ctl->n_rays[lp.level], lp.cap);
     if (GEN && blockIdx.x == 0 && threadIdx.x == 0) ctl->n_rays[0] = gp.n_slots;
@@ -1659,7 +1661,6 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         lp.last_level = (level == rec) ? 1 : 0;
         if (ctx->S.n_shadow_lights <= 0) return RT_OK;
         if (beam) {
-            HIP_TRY(ctx, hipMemsetAsync(bb.queue_n, 0, 3 * sizeof(uint32_t), s_));
             hipLaunchKernelGGL(k_beam_setup, dim3(gsz(ctx->g_beam_setup, ctx->nb_beam_setup, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
             hipLaunchKernelGGL(k_shadow_beam, dim3(gsz(ctx->g_beam, ctx->nb_beam, side)), block, 0, s_, ctx->S, lp, hb, bb, ctx->ctl);
             hipLaunchKernelGGL(k_shadow_queue, dim3(gsz(ctx->g_queue, ctx->nb_queue, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, sg, bb, ctx->ctl);
@@ -1670,16 +1671,17 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         }
         return RT_OK;
     };
-    auto intersect = [&](int level, hipStream_t s_, RayQ &qc, HitBuf &hb, double *fbx, int side) {
+    auto intersect = [&](int level, hipStream_t s_, RayQ &qc, HitBuf &hb, double *fbx, int side, BeamBuf &bb) {
+        uint32_t *bc = beam ? bb.queue_n : nullptr;
         lp.level = level;
         lp.last_level = (level == rec) ? 1 : 0;
         static const GenParams none{};
         int32_t *ids = level == 0 ? d_ids : nullptr;
         if (level == 0 && gen) {
-            if (fast) hipLaunchKernelGGL((k_intersect<true, true>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, *gen);
-            else hipLaunchKernelGGL((k_intersect<false, true>), dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, *gen);
-        } else if (fast) hipLaunchKernelGGL((k_intersect<true, false>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, none);
-        else hipLaunchKernelGGL((k_intersect<false, false>), dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, none);
+            if (fast) hipLaunchKernelGGL((k_intersect<true, true>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, *gen, bc);
+            else hipLaunchKernelGGL((k_intersect<false, true>), dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, *gen, bc);
+        } else if (fast) hipLaunchKernelGGL((k_intersect<true, false>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, none, bc);
+        else hipLaunchKernelGGL((k_intersect<false, false>), dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, none, bc);
     };
     auto queue_of = [&](int level) -> RayQ & { return level == 0 ? ctx->q[0] : ctx->q[1 + ((level - 1) & 1)]; };
 
@@ -1690,7 +1692,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
             BeamBuf &bb = level == 0 ? ctx->beam : ctx->beam1;
             const int e = 2 + 6 * level;
             PROF_MARK(e + 0);
-            intersect(level, st, qc, hb, level == 0 ? fb0 : ctx->fb, 0);
+            intersect(level, st, qc, hb, level == 0 ? fb0 : ctx->fb, 0, bb);
             PROF_MARK(e + 1);
             PROF_MARK(e + 2);
             if (int rc = shadows(level, st, qc, hb, level == 0 ? ctx->seg : ctx->seg1, bb, 0)) return rc;
@@ -1705,7 +1707,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         }
     } else {
         hipStream_t s2_ = ctx->stream2;
-        intersect(0, st, ctx->q[0], ctx->hb, fb0, 0);
+        intersect(0, st, ctx->q[0], ctx->hb, fb0, 0, ctx->beam);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
         HIP_TRY(ctx, hipStreamWaitEvent(s2_, ctx->ev_fork, 0));
         // level 0 (caller's stream) is submitted first: the host needs ~10 us per launch, and the long chain of the
@@ -1720,7 +1722,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                            ctx->beam.litbits, ctx->beam.pair_slot, ctx->beam.queue_n);
         for (int level = 1; level <= rec; ++level) {
             RayQ &qc = queue_of(level), &qn = queue_of(level + 1);
-            intersect(level, s2_, qc, ctx->hb1, ctx->fb, 2);
+            intersect(level, s2_, qc, ctx->hb1, ctx->fb, 2, ctx->beam1);
             if (int rc = shadows(level, s2_, qc, ctx->hb1, ctx->seg1, ctx->beam1, 2)) return rc;
             hipLaunchKernelGGL(k_shade<3>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s2_, ctx->S, lp, qc, qn, ctx->hb1, ctx->ctl, ctx->fb,
                                ctx->beam1.litbits, ctx->beam1.pair_slot, ctx->beam1.queue_n);
