@@ -263,7 +263,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_load_rays(const double *o, const d
 // overlap the traversal instead of costing a launch of their own (k_gen) before it.
 template <bool FAST, bool GEN>
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) k_intersect(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb,
-                                                        FrameCtl *ctl, double *fb, int32_t *ids_out, GenParams gp, uint32_t *beam_counters) {
+                                                        FrameCtl *ctl, double *fb, int32_t *ids_out, GenParams gp, uint32_t *beam_counters,
+                                                        double *fb_side) {
     extern __shared__ uint2 lds_stack[];
     uint2 *stk = lds_stack + threadIdx.x;
     if (ctl->overflow) return;                    // a queue overflowed earlier in this frame: the frame is void
@@ -282,8 +283,16 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
         uint32_t slot = RT_INVALID_SLOT;
         d3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
         if (GEN) {
+            // every output slot is visited exactly once here: the framebuffers are initialised by plain stores
+            // (fb: 0 or the background of a miss, below; fb_side: 0) instead of two memsets before the frame
+            const bool in_range = active;
             if (active) active = gen_ray(gp, q, k, o, d, slot);
             valid_total += active ? 1ull : 0ull;
+            const uint32_t zs = active ? slot : ((in_range && gp.world > 1) ? (uint32_t)k : RT_INVALID_SLOT);
+            if (zs != RT_INVALID_SLOT) {
+                if (!active) { fb[3ull * zs] = 0.0; fb[3ull * zs + 1] = 0.0; fb[3ull * zs + 2] = 0.0; }
+                if (fb_side) { fb_side[3ull * zs] = 0.0; fb_side[3ull * zs + 1] = 0.0; fb_side[3ull * zs + 2] = 0.0; }
+            }
         } else {
             slot = active ? q.slot[k] : RT_INVALID_SLOT;
             active = active && slot != RT_INVALID_SLOT;
@@ -298,9 +307,10 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
             if (ids_out && lp.level == 0) ids_out[slot] = h.id;
             if (h.id == 0) {
                 // ray_tracer.py:65,72,132: misses keep the background colour
-                d3 thr = GEN ? mk3(1.0, 1.0, 1.0) : mk3(q.tr[k], q.tg[k], q.tb[k]);
-                fb_add(fb, slot, thr * ld3(S.bg));
+                if (GEN) { fb[3ull * slot] = S.bg[0]; fb[3ull * slot + 1] = S.bg[1]; fb[3ull * slot + 2] = S.bg[2]; }   // = 0 + 1 * bg
+                else fb_add(fb, slot, mk3(q.tr[k], q.tg[k], q.tb[k]) * ld3(S.bg));
             } else {
+                if (GEN) { fb[3ull * slot] = 0.0; fb[3ull * slot + 1] = 0.0; fb[3ull * slot + 2] = 0.0; }
                 hb.px[k] = h.p.x; hb.py[k] = h.p.y; hb.pz[k] = h.p.z;
                 hb.id[k] = h.id;
                 has_hit = true;
@@ -1678,10 +1688,10 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         static const GenParams none{};
         int32_t *ids = level == 0 ? d_ids : nullptr;
         if (level == 0 && gen) {
-            if (fast) hipLaunchKernelGGL((k_intersect<true, true>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, *gen, bc);
-            else hipLaunchKernelGGL((k_intersect<false, true>), dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, *gen, bc);
-        } else if (fast) hipLaunchKernelGGL((k_intersect<true, false>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, none, bc);
-        else hipLaunchKernelGGL((k_intersect<false, false>), dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, none, bc);
+            if (fast) hipLaunchKernelGGL((k_intersect<true, true>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, *gen, bc, fbx != ctx->fb ? ctx->fb : nullptr);
+            else hipLaunchKernelGGL((k_intersect<false, true>), dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, *gen, bc, fbx != ctx->fb ? ctx->fb : nullptr);
+        } else if (fast) hipLaunchKernelGGL((k_intersect<true, false>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, none, bc, nullptr);
+        else hipLaunchKernelGGL((k_intersect<false, false>), dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, none, bc, nullptr);
     };
     auto queue_of = [&](int level) -> RayQ & { return level == 0 ? ctx->q[0] : ctx->q[1 + ((level - 1) & 1)]; };
 
@@ -1768,8 +1778,10 @@ extern "C" int rt_render_device(rt_ctx *ctx, const rt_render_params *p, float *d
     if (prof) { if (int rc = prof_prepare(ctx, rec + 1)) return rc; }
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
     HIP_TRY(ctx, hipMemsetAsync(ctx->ctl, 0, sizeof(FrameCtl), st));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->fb, 0, g.out_slots * 3 * sizeof(double), st));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->fb0, 0, g.out_slots * 3 * sizeof(double), st));
+    if (prof || rec < 0) {      // otherwise k_intersect(0) initialises both framebuffers while it makes the camera rays
+        HIP_TRY(ctx, hipMemsetAsync(ctx->fb, 0, g.out_slots * 3 * sizeof(double), st));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->fb0, 0, g.out_slots * 3 * sizeof(double), st));
+    }
     if (d_ids) HIP_TRY(ctx, hipMemsetAsync(d_ids, 0, g.out_slots * sizeof(int32_t), st));
     dim3 grid(ctx->grid), block(RT_BLOCK);
     if (rec < 0) {
