@@ -428,7 +428,8 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
     // atomic on the list counter per 64 pairs; see k_shadow_beam)
     uint32_t *lbuf = lbuf_all + (threadIdx.x >> 6) * 128, *obuf = obuf_all + (threadIdx.x >> 6) * 128;
     uint32_t ln = 0u, on = 0u;
-    auto store_listed = [&](uint32_t slot, uint32_t pair) { bb.list[slot] = pair; bb.pair_slot[pair] = slot; };
+    // pair_slot is laid out [shadow light][hit slot]: a wave's 64 hits of one light store / load one 256-byte run
+    auto store_listed = [&](uint32_t slot, uint32_t pair) { bb.list[slot] = pair; const uint32_t hh = pair / nsl; bb.pair_slot[(uint64_t)(pair - hh * nsl) * lp.cap + hh] = slot; };
     auto store_ovf = [&](uint32_t slot, uint32_t pair) { bb.ovlist[slot] = pair; };
     // A wave takes 64 CONSECUTIVE HITS and ONE light: neighbouring hits (neighbouring pixels at level 0) send
     // nearly the same beam through the tree, the lanes of a wave stay on one path.
@@ -452,7 +453,8 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
             float4 *rec = bb.rec + (uint64_t)seg * RT_PAIR_UNITS;
             // D = -(light - P)/|light - P|  (Light.py:81: light_direction = -L)
             const float e0 = (float)dl.x, e1 = (float)dl.y, e2 = (float)dl.z;
-            const float il = 1.0f / sqrtf(fmaf(e0, e0, fmaf(e1, e1, e2 * e2)));
+            // (rsq / rcp: 1 ulp each, like the correctly rounded sqrt + divide they replace; all inside RT_RHO)
+            const float il = __builtin_amdgcn_rsqf(fmaf(e0, e0, fmaf(e1, e1, e2 * e2)));
             const float D0 = -e0 * il, D1 = -e1 * il, D2 = -e2 * il;
             // util.get_orthonormal_vector: the branch is taken on the float64 value of D.z (Q7)
             const double az = fabs(dl.z), an = fabs(dl.x) + fabs(dl.y) + az;
@@ -460,12 +462,12 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
             float u0 = 1.0f, u1 = 1.0f, u2 = 0.0f;
             if (dl.z != 0.0) {
                 if (az < 1e-280 * an || fabsf(D2) < 1e-12f) delicate = true;   // D.z would underflow, or (1,1,u3) overflows float32
-                u2 = -(D0 + D1) / D2;
+                u2 = -(D0 + D1) * __builtin_amdgcn_rcpf(D2);
             }
-            const float iu = 1.0f / sqrtf(2.0f + u2 * u2);
+            const float iu = __builtin_amdgcn_rsqf(2.0f + u2 * u2);
             u0 *= iu; u1 *= iu; u2 *= iu;
             float r0 = u1 * D2 - u2 * D1, r1 = u2 * D0 - u0 * D2, r2 = u0 * D1 - u1 * D0;     // np.cross(up, D)
-            const float ir = 1.0f / (sqrtf(fmaf(r0, r0, fmaf(r1, r1, r2 * r2))) + 1e-6f);
+            const float ir = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(r0, r0, fmaf(r1, r1, r2 * r2))) + 1e-6f);
             r0 *= ir; r1 *= ir; r2 *= ir;
             const float radius = (float)Lt.radius;
             const float g = radius / (float)lp.sh_rays;
@@ -516,17 +518,17 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                 if (bo.overflow) atomicAdd(&ctl->dbg_why[delicate ? 0 : bo.why], 1u);
             }
             // every |sample - P| inside the per-ray filter's range (k_shadow_beam: 1e-4 < nv < 1e7)
-            const float sc = sqrtf(fmaf(cB0, cB0, fmaf(cB1, cB1, cB2 * cB2))), sh = sqrtf(fmaf(h0, h0, fmaf(h1, h1, h2 * h2)));
-            const bool range_ok = sc - sh > 1e-3f && sc + sh < 1e6f;
+            const float sc = __builtin_amdgcn_sqrtf(fmaf(cB0, cB0, fmaf(cB1, cB1, cB2 * cB2))), sh = __builtin_amdgcn_sqrtf(fmaf(h0, h0, fmaf(h1, h1, h2 * h2)));
+            const bool range_ok = sc - sh > 1.1e-3f && sc + sh < 0.9e6f;
             uint32_t whole = 0;                             // RT_PAIR_LIT / RT_PAIR_UNLIT when decided
             if (!bo.overflow && range_ok) {
                 if (bo.occ_all) whole = RT_PAIR_UNLIT;
                 else if (bo.nu == 0 && n_eval == 0) whole = (n_atp + (bo.atp_all ? 1u : 0u)) > 0 ? RT_PAIR_LIT : RT_PAIR_UNLIT;
             }
-            if (whole) bb.pair_slot[seg] = whole;
+            if (whole) bb.pair_slot[(uint64_t)ml * lp.cap + h] = whole;
             else if (bo.overflow) {                         // all its rays go to the float64 kernel, which expands the pair itself
                 ovf = true;
-                bb.pair_slot[seg] = RT_PAIR_UNLIT;          // nothing from the filter: the lit count is the queue kernel's alone
+                bb.pair_slot[(uint64_t)ml * lp.cap + h] = RT_PAIR_UNLIT;   // nothing from the filter: the lit count is the queue kernel's alone
             } else {
                 listed = true;                              // only now the header is worth its 64 bytes (13 % of the pairs)
                 const uint32_t meta = bo.nu | (bo.boxmask << 8) | ((uint32_t)m << 16) | (pcls << 24) | (bo.atp_all ? 1u << 30 : 0u);
@@ -909,7 +911,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, LevelParams lp, Ra
                     uint32_t cnt = hb.lit[seg];
                     hb.lit[seg] = 0;                                     // ready for the next level
                     if (lp.beam) {                                       // + the beam path's verdicts
-                        const uint32_t ps = pair_slot[seg];
+                        const uint32_t ps = pair_slot[(uint64_t)ml * lp.cap + h];
                         const uint32_t ss = (uint32_t)(lp.sh_rays * lp.sh_rays);
                         if (ps == RT_PAIR_LIT) cnt += ss;
                         else if (ps != RT_PAIR_UNLIT) {                  // listed: lanes [lo, lo + s*s) of the slot's chunk
