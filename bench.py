@@ -43,6 +43,10 @@ def build_scene(workload):
         text = gen_scene.synth_spheres(100, 1234, 5, 5)
     elif workload == "synth400":
         text = gen_scene.synth_spheres(20, 1234, 5, 5)
+    elif workload == "synth1M":
+        text = gen_scene.synth_mixed(1000, 4321, 5, 10)           # BASELINE.json configs[4]: 1M spheres/boxes, R = 10
+    elif workload == "synth90k":
+        text = gen_scene.synth_mixed(300, 4321, 5, 10)
     elif workload == "pool":
         return Scene.from_file(os.path.join(ROOT, "tests", "golden", "scenes", "pool.txt"))
     elif workload == "original":

@@ -1308,6 +1308,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
     {
         std::vector<KNode> kn(nn);
         std::vector<LeafF> lf((size_t)s->n_leaf_refs);
+        std::vector<uint32_t> prim_entry((size_t)ns + nb + 1, 0u);
         bool ok = true;
         std::vector<int> depth(nn, 0);
         int max_depth = 1;
@@ -1341,8 +1342,9 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
             kn[i].b = ((uint32_t)R << 2) | (uint32_t)axis;
         }
         if (max_depth > 64) ok = false;   // per-lane stacks (8 B per level and lane) must fit the 160 KB LDS
-        for (int e = 0; e < s->n_leaf_refs; ++e) {
+        for (int e = s->n_leaf_refs - 1; e >= 0; --e) {           // (descending: prim_entry ends up with the first entry)
             const int p = s->leaf_prim[e];
+            if (p >= 0 && p < ns + nb) prim_entry[p] = (uint32_t)e;
             LeafF &f = lf[e];
             memset(&f, 0, sizeof(f));
             if (p < ns) {
@@ -1362,6 +1364,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
         if ((size_t)ns + nb >= (1u << 30)) ok = false;
         TRY_C(upload(ctx, ctx->scene_allocs, kn, &ctx->F.knodes));
         TRY_C(upload(ctx, ctx->scene_allocs, lf, &ctx->F.leaves));
+        TRY_C(upload(ctx, ctx->scene_allocs, prim_entry, &ctx->F.prim_entry));
         float ext = 0;
         for (int k = 0; k < 3; ++k) {
             ctx->F.root_lo[k] = round_down(s->node_lo[k]);

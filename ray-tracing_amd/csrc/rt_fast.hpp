@@ -43,6 +43,7 @@ struct LeafF {      // 32 B, one per leaf entry, in leaf-list order
 struct FastScene {
     const KNode *knodes;
     const LeafF *leaves;
+    const uint32_t *prim_entry;     // primitive number -> one of its leaf entries (its LeafF record)
     float root_lo[3], root_hi[3];   // rounded outward
     float extent;                   // max |coordinate| of the root box, rounded up
     int32_t depth;                  // tree depth = stack entries needed per lane

@@ -254,7 +254,8 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
     if (!(l0 <= l1)) return R;
 
     // ---- phase 1: traversal.  The loops carry only the traversal state; a leaf entry that passes the float32
-    // tests is parked in the lane's LDS list tl[] (RT_TOUCH entries) and looked at after the traversal.
+    // tests is parked (its primitive number, once) in the lane's LDS list tl[] (RT_TOUCH entries) and looked at
+    // after the traversal.
     const uint32_t NONE = 0xffffffffu;
     uint32_t node = 0, nt = 0, ntu = 0;              // touched entries, and the candidate units they would need
     int sp = 0;
@@ -299,20 +300,30 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
                                    !(c2 - rr > bhi2) && !(d2 + rr < blo2);
                 if (touch) {
                     bool in_cone = true;
-                    if (sph && cone_ok) {
-                        // sphere against the cone: distance to the axis <= r (1 + tan) + axial position * tan (conservative).
-                        // The distance comes from the cross product: its error is ~1e-7 |c|, inside the 2e-6 |c| below.
-                        const float ta = fmaf(c0, ax0, fmaf(c1, ax1, c2 * ax2));
-                        const float k0 = fmaf(c1, ax2, -(c2 * ax1)), k1 = fmaf(c2, ax0, -(c0 * ax2)), k2 = fmaf(c0, ax1, -(c1 * ax0));
+                    if (cone_ok) {
+                        // sphere (a box: its bounding sphere) against the cone: distance to the axis <= r (1 + tan) +
+                        // axial position * tan (conservative).  The distance comes from the cross product: its error
+                        // is ~1e-7 |c|, inside the 2e-6 |c| below.
+                        const float m0_ = sph ? c0 : 0.5f * (c0 + d0), m1_ = sph ? c1 : 0.5f * (c1 + d1), m2_ = sph ? c2 : 0.5f * (c2 + d2);
+                        const float e0_ = d0 - c0, e1_ = d1 - c1, e2_ = d2 - c2;
+                        const float rb = sph ? lf.r : 0.5f * __builtin_amdgcn_sqrtf(fmaf(e0_, e0_, fmaf(e1_, e1_, e2_ * e2_))) * 1.000001f;
+                        const float ta = fmaf(m0_, ax0, fmaf(m1_, ax1, m2_ * ax2));
+                        const float k0 = fmaf(m1_, ax2, -(m2_ * ax1)), k1 = fmaf(m2_, ax0, -(m0_ * ax2)), k2 = fmaf(m0_, ax1, -(m1_ * ax0));
                         const float dp2 = fmaf(k0, k0, fmaf(k1, k1, k2 * k2));
-                        const float cn = (fabsf(c0) + fabsf(c1)) + fabsf(c2);         // >= |c|
-                        const float lim = fmaf(lf.r, 1.0f + kt, fmaxf(ta, 0.0f) * kt) + E + 2e-6f * cn;
-                        in_cone = !(dp2 > lim * lim * 1.0001f) && !(ta < -(lf.r + E)) && !(ta > ax_len * (1.0f + kt) + lf.r + E);
+                        const float cn = (fabsf(m0_) + fabsf(m1_)) + fabsf(m2_);      // >= |centre|
+                        const float lim = fmaf(rb, 1.0f + kt, fmaxf(ta, 0.0f) * kt) + E + 2e-6f * cn;
+                        in_cone = !(dp2 > lim * lim * 1.0001f) && !(ta < -(rb + E)) && !(ta > ax_len * (1.0f + kt) + rb + E);
                     }
                     if (in_cone) {
-                        if (nt < RT_TOUCH) tl[nt * STRIDE] = e;
-                        ++nt;
-                        ntu += sph ? 1u : 2u;
+                        const uint32_t prim = lf.pk >> 2;
+                        bool seen = false;               // a primitive is listed in every leaf it reaches into
+#pragma unroll
+                        for (uint32_t j = 0; j < RT_TOUCH; ++j) seen = seen || (j < nt && tl[j * STRIDE] == prim);
+                        if (!seen) {
+                            if (nt < RT_TOUCH) tl[nt * STRIDE] = prim;
+                            ++nt;
+                            ntu += sph ? 1u : 2u;
+                        }
                     }
                 }
             }
@@ -325,14 +336,10 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
     }
     if (nt > RT_TOUCH || ntu > RT_CUNITS + 4u || (dbg & 0x2000)) { R.overflow = true; R.why = 1; return R; }
 
-    // ---- phase 2: the touched entries.  Cone test, duplicates (a primitive is listed in several leaves),
-    // whole-pair verdicts, float64 re-expression.
-    uint32_t n = 0, nu = 0, boxmask = 0;             // candidates seen, units used, which units start a box
-    uint32_t ids[RT_CMAX];                           // registers (static indices only): the pair's candidates so far
-#pragma unroll
-    for (uint32_t j = 0; j < RT_CMAX; ++j) ids[j] = 0xffffffffu;
+    // ---- phase 2: the touched primitives.  Whole-pair verdicts, float64 re-expression.
+    uint32_t nu = 0, boxmask = 0;                    // units used, which units start a box
     for (uint32_t k = 0; k < nt; ++k) {
-        const LeafF lf = F.leaves[tl[k * STRIDE]];
+        const LeafF lf = F.leaves[F.prim_entry[tl[k * STRIDE]]];
         const uint32_t kind = lf.pk & 3u, prim = lf.pk >> 2;
         const bool sph = kind == 1u;
         const float c0 = lf.x - Pf0, c1 = lf.y - Pf1, c2 = lf.z - Pf2;
@@ -343,10 +350,6 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
             dp2 = fmaf(k0, k0, fmaf(k1, k1, k2 * k2));
             cn = (fabsf(c0) + fabsf(c1)) + fabsf(c2);                             // >= |c|
         }
-        bool seen = false;
-#pragma unroll
-        for (uint32_t j = 0; j < RT_CMAX; ++j) seen = seen || (j < n && ids[j] == prim);
-        if (seen) continue;
         const DPrim *pr = S.prims + prim;
         bool store = true;
         double dx = 0, dy = 0, dz = 0, cd = 0;
@@ -392,10 +395,6 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
                 nu += 2;
             }
         }
-        if (n >= RT_CMAX) { R.overflow = true; R.why = 3; return R; }                       // the dedup list is full
-#pragma unroll
-        for (uint32_t j = 0; j < RT_CMAX; ++j) if (j == n) ids[j] = prim;
-        ++n;
     }
     R.nu = nu; R.boxmask = boxmask;
     return R;
