@@ -382,15 +382,57 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
                 }
             }
         }
+        float bl0 = 0, bl1 = 0, bl2 = 0, bh0 = 0, bh1 = 0, bh2 = 0;
+        if (!sph) {
+            // box relative to P, rounded outward (float64 difference first)
+            bl0 = __double2float_rd(pr->a[0] - P.x); bl1 = __double2float_rd(pr->a[1] - P.y); bl2 = __double2float_rd(pr->a[2] - P.z);
+            bh0 = __double2float_ru(pr->b[0] - P.x); bh1 = __double2float_ru(pr->b[1] - P.y); bh2 = __double2float_ru(pr->b[2] - P.z);
+            if (cone_ok) {
+                // whole-pair verdicts for a box.  (1) every ray misses its bounding sphere (same rectangle test as for
+                // spheres).  (2) P lies in the interior of one of its faces (|face - P| < 1e-9 along axis k, > 1e-5 from
+                // the other five planes): with every sample on the outer side of that face (|w_k| >= 1e-2) the light ray
+                // arrives at P from outside, tau_out = (face - P)_k / w_k, |tau_out| < 1e-7 -> AT_P; with every sample on
+                // the inner side it has to cross the box first, tau_out >= min(thickness, 1e-5) and <= its diagonal ->
+                // OCCLUDE (when the box ends before the nearest sample).
+                const float m0_ = 0.5f * (bl0 + bh0), m1_ = 0.5f * (bl1 + bh1), m2_ = 0.5f * (bl2 + bh2);
+                const float e0_ = bh0 - bl0, e1_ = bh1 - bl1, e2_ = bh2 - bl2;
+                const float diag = __builtin_amdgcn_sqrtf(fmaf(e0_, e0_, fmaf(e1_, e1_, e2_ * e2_))) * 1.000001f, rb = 0.5f * diag;
+                const float tab = fmaf(m0_, ax0, fmaf(m1_, ax1, m2_ * ax2));
+                const float cnb = (fabsf(m0_) + fabsf(m1_)) + fabsf(m2_);
+                if (tab > 0.0f) {
+                    const float tm = (tab + E) * __builtin_amdgcn_rcpf(ax_len - Q.ja) * 1.00001f * Q.aq + E;
+                    const float cu = fabsf(fmaf(m0_, Q.u0, fmaf(m1_, Q.u1, m2_ * Q.u2))), cr = fabsf(fmaf(m0_, Q.r0, fmaf(m1_, Q.r1, m2_ * Q.r2)));
+                    const float ex = fmaxf(cu - tm - 2e-6f * cnb, 0.0f), ey = fmaxf(cr - tm - 2e-6f * cnb, 0.0f);
+                    const float rl = fmaf(rb, fmaf(0.5f * kt, kt, 1.001f), E);
+                    if (fmaf(ex, ex, ey * ey) > rl * rl) continue;
+                }
+                const float smax = ax_len + __builtin_amdgcn_sqrtf(hh2) * 1.000001f;            // >= |sample|
+                const float wm = 1e-2f * smax;
+                const float tiny = 1e-9f, clear = 1e-5f;
+                const bool in0 = bl0 < -clear && bh0 > clear, in1 = bl1 < -clear && bh1 > clear, in2 = bl2 < -clear && bh2 > clear;
+                // which face, if any: 0 none, +-(k+1)
+                int face = 0;
+                if (in1 && in2) { if (fabsf(bh0) < tiny && bl0 < -clear) face = 1; else if (fabsf(bl0) < tiny && bh0 > clear) face = -1; }
+                if (in0 && in2) { if (fabsf(bh1) < tiny && bl1 < -clear) face = 2; else if (fabsf(bl1) < tiny && bh1 > clear) face = -2; }
+                if (in0 && in1) { if (fabsf(bh2) < tiny && bl2 < -clear) face = 3; else if (fabsf(bl2) < tiny && bh2 > clear) face = -3; }
+                if (face != 0) {
+                    const int k = face > 0 ? face - 1 : -face - 1;
+                    const float Lk = sel3((uint32_t)k, L0, L1, L2), Uk = sel3((uint32_t)k, U0, U1, U2);
+                    const bool outer = face > 0 ? Lk >= wm : Uk <= -wm;          // every sample beyond the face, outside the box
+                    const bool inner = face > 0 ? Uk <= -wm : Lk >= wm;          // every sample on the box's side of the face
+                    if (outer) { R.atp_all = true; store = false; }
+                    else if (inner && diag * 1.0001f + 1e-4f < smin) { R.occ_all = true; return R; }
+                }
+            }
+        }
         if (store) {
             if (nu + kind > RT_CUNITS) { R.overflow = true; R.why = 2; return R; }          // kind == units needed (sphere 1, box 2)
             if (sph) {
                 out[nu] = make_float4((float)dx, (float)dy, (float)dz, (float)cd);
                 nu += 1;
             } else {
-                out[nu] = make_float4(__double2float_rd(pr->a[0] - P.x), __double2float_rd(pr->a[1] - P.y),
-                                      __double2float_rd(pr->a[2] - P.z), __double2float_ru(pr->b[0] - P.x));
-                out[nu + 1] = make_float4(__double2float_ru(pr->b[1] - P.y), __double2float_ru(pr->b[2] - P.z), 0.0f, 0.0f);
+                out[nu] = make_float4(bl0, bl1, bl2, bh0);
+                out[nu + 1] = make_float4(bh1, bh2, 0.0f, 0.0f);
                 boxmask |= 1u << nu;
                 nu += 2;
             }
