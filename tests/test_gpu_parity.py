@@ -309,3 +309,34 @@ def test_overlapped_levels_equal_sequential_levels(gpu_ctx, tag, w, h, sh, rec):
         assert np.array_equal(ovl["rgb"], seq["rgb"])
         for key in ("rays", "shadow_rays", "reflect_rays", "transmit_rays", "hits"):
             assert ovl["stats"][key] == seq["stats"][key], key
+
+
+def test_mixed_lattice_with_transparency_equals_exact_walk(oracle):
+    """BASELINE.json configs[4] in small: spheres and boxes alternating on a lattice, 25 % reflective, 15 % transparent,
+    recursion 10 (tools/gen_scene.synth_mixed, grid 40 = 1600 primitives).  Default path == exact walk bit for bit,
+    and == the oracle on the 8-bit frame."""
+    import sys
+    import tempfile
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_scene
+    from ray_tracing_amd.render import Scene
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        f.write(gen_scene.synth_mixed(40, 4321, 5, 10))
+    try:
+        sc = Scene.from_file(f.name)
+    finally:
+        os.unlink(f.name)
+    with native.Context(sc.packed, device=0) as ctx:
+        for sh, rec, w, h in ((5, 10, 240, 135), (3, 4, 320, 180)):
+            common = dict(sh_rays=sh, rec_max=rec, jitter=True, seed=21)
+            exact = ctx.render(abi.render_params(w, h, flags=abi.RT_FLAG_EXACT_TRAVERSAL, **common))
+            fast = ctx.render(abi.render_params(w, h, **common))
+            assert np.array_equal(fast["ids"], exact["ids"])
+            assert fast["stats"]["rays"] == exact["stats"]["rays"]
+            assert np.array_equal(fast["rgb"], exact["rgb"])
+        p = abi.render_params(96, 54, sh_rays=3, rec_max=6, jitter=True, seed=5)
+        out = ctx.render(p)
+        ref = oracle.render(sc.packed, p)
+        assert np.array_equal(out["ids"], ref["ids"])
+        assert np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
+        assert out["stats"]["rays"] == ref["counters"]["rays"]
