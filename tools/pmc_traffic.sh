@@ -8,7 +8,7 @@ mkdir -p gpurun_out/$out
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout -s KILL 120 rocprofv3 --pmc $grp --output-format csv -d gpurun_out/$out/pass$i -- python tools/prof_frame.py "$@" > gpurun_out/$out/pass$i.log 2>&1
+  timeout -s KILL 400 rocprofv3 --pmc $grp --output-format csv -d gpurun_out/$out/pass$i -- python tools/prof_frame.py "$@" > gpurun_out/$out/pass$i.log 2>&1
   echo "pass $i rc=$?"
 done
 python tools/pmc_summary.py gpurun_out/$out
