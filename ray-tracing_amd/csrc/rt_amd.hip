@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
     uint32_t *lbuf = lbuf_all + (threadIdx.x >> 6) * 128, *obuf = obuf_all + (threadIdx.x >> 6) * 128;
     uint32_t ln = 0u, on = 0u;
     // pair_slot is laid out [shadow light][hit slot]: a wave's 64 hits of one light store / load one 256-byte run
-    auto store_listed = [&](uint32_t slot, uint32_t pair) { bb.list[slot] = pair; const uint32_t hh = pair / nsl; bb.pair_slot[(uint64_t)(pair - hh * nsl) * lp.cap + hh] = slot; };
+    auto store_listed = [&](uint32_t slot, uint32_t v) { bb.list[slot] = v; const uint32_t pair = v & ((1u << RT_LIST_NU_SHIFT) - 1u); const uint32_t hh = pair / nsl; bb.pair_slot[(uint64_t)(pair - hh * nsl) * lp.cap + hh] = slot; };
     auto store_ovf = [&](uint32_t slot, uint32_t pair) { bb.ovlist[slot] = pair; };
     // A wave takes 64 CONSECUTIVE HITS and ONE light: neighbouring hits (neighbouring pixels at level 0) send
     // nearly the same beam through the tree, the lanes of a wave stay on one path.
@@ -444,6 +444,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
         const bool valid = hblk < hit_blocks && h < n_hits;
         const uint32_t seg = h * nsl + ml;
         bool listed = false, ovf = false;
+        uint32_t list_nu = 0u;
         if (valid) {
             const uint32_t r = hb.list[h];
             const int m = S.shadow_lights[ml];
@@ -531,14 +532,15 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                 bb.pair_slot[(uint64_t)ml * lp.cap + h] = RT_PAIR_UNLIT;   // nothing from the filter: the lit count is the queue kernel's alone
             } else {
                 listed = true;                              // only now the header is worth its 64 bytes (13 % of the pairs)
-                const uint32_t meta = bo.nu | (bo.boxmask << 8) | ((uint32_t)m << 16) | (pcls << 24) | (bo.atp_all ? 1u << 30 : 0u);
+                const uint32_t meta = bo.nu | (bo.boxmask << 4) | ((uint32_t)m << 16) | (pcls << 24) | (bo.atp_all ? 1u << 30 : 0u);
+                list_nu = bo.nu;
                 rec[0] = make_float4(q00, q01, q02, g);
                 rec[1] = make_float4(u0, u1, u2, __uint_as_float(meta));
                 rec[2] = make_float4(r0, r1, r2, __uint_as_float(q.gpix[r]));
                 rec[3] = make_float4(pd[0], pd[1], pd[2], __uint_as_float(q.path[r]));
             }
         }
-        wave_append(listed, seg, lbuf, ln, &bb.queue_n[1], lane, store_listed);
+        wave_append(listed, seg | (list_nu << RT_LIST_NU_SHIFT), lbuf, ln, &bb.queue_n[1], lane, store_listed);
         wave_append(ovf, seg, obuf, on, &bb.queue_n[2], lane, store_ovf);
     }
     wave_append_flush(lbuf, ln, &bb.queue_n[1], lane, store_listed);
@@ -634,7 +636,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene S, FastScene F, Leve
 // the records of chunk i+1 are in flight (parked in registers until the top of the next iteration) and so are
 // the pair numbers of chunk i+2.
 // The lane -> (pair, sample) map is the same in every chunk.
-#define RT_WAVE_UNITS 128
+#define RT_WAVE_UNITS 192
 __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams lp, HitBuf hb, BeamBuf bb, FrameCtl *ctl) {
     __shared__ float4 pair_lds_all[(RT_BLOCK / 64) * RT_WAVE_UNITS];
     __shared__ unsigned long long qbuf_all[(RT_BLOCK / 64) * 128];
@@ -666,9 +668,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
     const uint32_t mypair = sib < lp.spb ? sib - wp0 : 63u;            // lane 63 never fetches a pair number: NONE
     const float4 *rec = pair_lds + (sib < lp.spb ? (sib - wp0) * RT_PAIR_UNITS : 0u);
     // staging: unit i of the wave's slice = unit i % 12 of its pair i / 12
-    const uint32_t i0u = (uint32_t)lane, i1u = (uint32_t)lane + 64u;
-    const uint32_t sp0 = i0u / RT_PAIR_UNITS, su0 = i0u - sp0 * RT_PAIR_UNITS, sp1 = i1u / RT_PAIR_UNITS, su1 = i1u - sp1 * RT_PAIR_UNITS;
-    const bool has0 = sp0 < npw, has1 = sp1 < npw;
+    const uint32_t i0u = (uint32_t)lane, i1u = (uint32_t)lane + 64u, i2u = (uint32_t)lane + 128u;
+    const uint32_t sp0 = i0u / RT_PAIR_UNITS, su0 = i0u % RT_PAIR_UNITS, sp1 = i1u / RT_PAIR_UNITS, su1 = i1u % RT_PAIR_UNITS,
+                   sp2 = i2u / RT_PAIR_UNITS, su2 = i2u % RT_PAIR_UNITS;
+    const bool has0 = sp0 < npw, has1 = sp1 < npw, has2 = sp2 < npw;
     // Lit verdicts leave as one 64-bit ballot per wave and chunk (k_shade counts the bits of a pair).  No global
     // atomic or store sits in the steady-state loop - the wait for the staged loads at the top of an iteration
     // would otherwise also wait for them (one vmcnt) - : lane l of the wave parks the ballot of iteration
@@ -679,12 +682,15 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
     for (int k = 0; k < RT_PMAX; ++k)
         for (int c = 0; c < 3; ++c) pn[k][c] = k < S.n_planes ? (float)S.planes[k].n[c] : 0.0f;
     const uint32_t zkey = lp.seed * 0x85EBCA6Bu + kk;
-    float4 st0 = make_float4(0, 0, 0, 0), st1 = st0;
+    float4 st0 = make_float4(0, 0, 0, 0), st1 = st0, st2 = st0;
 #define RT_LOAD_PAIRNO(dst_, chunk_) do { const uint32_t sl_ = (chunk_) * lp.spb + wp0 + (uint32_t)lane; \
         dst_ = ((uint32_t)lane < npw && sl_ < nlist) ? bb.list[sl_] : NONE; } while (0)
-#define RT_LOAD_RECS(pairno_) do { const uint32_t g0_ = __shfl((pairno_), (int)sp0), g1_ = __shfl((pairno_), (int)sp1); \
-        if (has0 && g0_ != NONE) st0 = bb.rec[(uint64_t)g0_ * RT_PAIR_UNITS + su0]; \
-        if (has1 && g1_ != NONE) st1 = bb.rec[(uint64_t)g1_ * RT_PAIR_UNITS + su1]; } while (0)
+    // a list entry = pair | units used << 28: only the header and the used candidate units of a record are fetched
+#define RT_LOAD_RECS(pairno_) do { const uint32_t g0_ = __shfl((pairno_), (int)sp0), g1_ = __shfl((pairno_), (int)sp1), g2_ = __shfl((pairno_), (int)sp2); \
+        const uint32_t pm_ = (1u << RT_LIST_NU_SHIFT) - 1u; \
+        if (has0 && g0_ != NONE && su0 < 4u + (g0_ >> RT_LIST_NU_SHIFT)) st0 = bb.rec[(uint64_t)(g0_ & pm_) * RT_PAIR_UNITS + su0]; \
+        if (has1 && g1_ != NONE && su1 < 4u + (g1_ >> RT_LIST_NU_SHIFT)) st1 = bb.rec[(uint64_t)(g1_ & pm_) * RT_PAIR_UNITS + su1]; \
+        if (has2 && g2_ != NONE && su2 < 4u + (g2_ >> RT_LIST_NU_SHIFT)) st2 = bb.rec[(uint64_t)(g2_ & pm_) * RT_PAIR_UNITS + su2]; } while (0)
     uint32_t cur = 0u, nxt = 0u, pno_cur = NONE, pno_nxt = NONE;
     bool have = walk.next(first), have_n = false;
     if (have) {
@@ -702,6 +708,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
         __builtin_amdgcn_wave_barrier();
         if (has0) pair_lds[i0u] = st0;
         if (has1) pair_lds[i1u] = st1;
+        if (has2) pair_lds[i2u] = st2;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -715,14 +722,15 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
                 RT_LOAD_PAIRNO(pno_n2, n2);
             }
         }
-        const uint32_t seg = __shfl(pno_cur, (int)mypair);            // the lane's (hit, light) pair
-        const bool active = seg != NONE;
+        const uint32_t ent = __shfl(pno_cur, (int)mypair);            // the lane's (hit, light) pair
+        const bool active = ent != NONE;
+        const uint32_t seg = ent & ((1u << RT_LIST_NU_SHIFT) - 1u);
         bool lit = false, unsure = false;
         if (active && !(lp.flags & 0x200)) {
             const float4 h0 = rec[0], h1 = rec[1], h2 = rec[2], h3 = rec[3];
             const float g = h0.w;
             const uint32_t meta = __float_as_uint(h1.w);
-            const uint32_t nu = (lp.flags & 0x400) ? 0u : meta & 0xffu, boxmask = (meta >> 8) & 0xffu;
+            const uint32_t nu = (lp.flags & 0x400) ? 0u : meta & 0xfu, boxmask = (meta >> 4) & 0xfffu;
             if (nu == RT_META_OVERFLOW) unsure = true;
             else {
                 float j10 = 0, j11 = 0, j12 = 0, j20 = 0, j21 = 0, j22 = 0;   // Light.py:277-278: one deviation per component
@@ -1652,7 +1660,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
     const uint32_t s2 = (uint32_t)(sh * sh);
     const bool beam = fast && ctx->S.n_planes <= RT_PMAX && !(p->flags & RT_FLAG_NO_BEAM) && s2 >= 9 && s2 <= RT_BLOCK &&
                       ctx->S.n_lights <= 256 &&   // pair record: 8-bit light index
-                      ctx->cap * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1) < 0xFFFFFFFFull;
+                      ctx->cap * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1) < (1ull << RT_LIST_NU_SHIFT);   // list entry: pair | units << 28
     if (s2 > 0 && s2 <= RT_BLOCK) {
         lp.spb = RT_BLOCK / s2;
         lp.beam = beam ? 1 : 0;
@@ -1866,10 +1874,10 @@ extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
             uint64_t hist[RT_CUNITS + 2] = {0}, evalp = 0, base = 0;
             for (uint32_t i = 0; i < n; ++i) {
                 float4 u1;
-                if (hipMemcpy(&u1, ctx->beam.rec + (uint64_t)lst[i] * RT_PAIR_UNITS + 1, sizeof(u1), hipMemcpyDeviceToHost) != hipSuccess) break;
+                if (hipMemcpy(&u1, ctx->beam.rec + (uint64_t)(lst[i] & ((1u << RT_LIST_NU_SHIFT) - 1u)) * RT_PAIR_UNITS + 1, sizeof(u1), hipMemcpyDeviceToHost) != hipSuccess) break;
                 uint32_t meta;
                 memcpy(&meta, &u1.w, 4);
-                uint32_t nu = meta & 0xff;
+                uint32_t nu = meta & 0xf;
                 hist[nu > RT_CUNITS ? RT_CUNITS + 1 : nu]++;
                 evalp += ((meta >> 24) & 3u) == 0u;
                 base += (meta >> 30) & 1u;

@@ -22,11 +22,11 @@
 #include <hip/hip_fp16.h>
 #include "rt_fast.hpp"
 
-#define RT_CUNITS 8          // 16-byte candidate units kept per (hit, light) pair: a sphere takes 1, a box 2
+#define RT_CUNITS 12         // 16-byte candidate units kept per (hit, light) pair: a sphere takes 1, a box 2
 #define RT_CMAX RT_CUNITS
 #define RT_TOUCH 8          // leaf entries a pair's traversal may park before its rays go to the float64 queue
 #define RT_PMAX 3            // planes handled by the filtered path
-#define RT_PAIR_UNITS (4 + RT_CUNITS)   // one pair record = 12 float4 = 192 B, contiguous
+#define RT_PAIR_UNITS (4 + RT_CUNITS)   // one pair record = 16 float4 = 256 B, contiguous; only 4 + units used are read
 
 // Pair record (float4 units), coordinates relative to P:
 //   u0 = {q0.xyz (p00 - P, Light.py:260), g = radius / s}
@@ -53,7 +53,8 @@ struct BeamBuf {
 };
 #define RT_PAIR_LIT 0xFFFFFFFFu
 #define RT_PAIR_UNLIT 0xFFFFFFFEu
-#define RT_META_OVERFLOW 0xFFu
+#define RT_META_OVERFLOW 0xFu
+#define RT_LIST_NU_SHIFT 28   // bb.list entry = pair | units used << 28 (the host keeps pairs < 2^28 on this path)
 
 #define RT_T1 1e-6f          // the reference's EPSILON (Light.py:221)
 #define RT_RHO 1.9073486e-06f   // 2^-19: bound on the ABSOLUTE error of the float32 unit direction w (measured need ~5e-7)
