@@ -1670,10 +1670,11 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
     const bool overlap = fast && !prof && rec >= 1 && fb0 != ctx->fb && ctx->two_sets && !(p->flags & RT_FLAG_NO_OVERLAP) && ctx->n_cu >= 8;
     static const int ovl_main = getenv("RT_AMD_OVL_MAIN") ? atoi(getenv("RT_AMD_OVL_MAIN")) : 3;   // workgroups per CU, level-0 side
     static const int ovl_side = getenv("RT_AMD_OVL_SIDE") ? atoi(getenv("RT_AMD_OVL_SIDE")) : 1;   // deeper levels
+    static const int ovl_main2 = getenv("RT_AMD_OVL_MAIN2") ? atoi(getenv("RT_AMD_OVL_MAIN2")) : 3;  // level-0 kernels after the beam setup (side 3)
     // grid of a kernel with nb workgroups per CU at full occupancy: side 0 = sequential, 1 = level-0 side, 2 = deeper levels
     auto gsz = [&](int full, int nb, int side) {
         if (!overlap || side == 0) return full;
-        int lim = side == 1 ? ovl_main : ovl_side;
+        int lim = side == 1 ? ovl_main : (side == 3 ? ovl_main2 : ovl_side);
         int use = nb < lim ? nb : lim;
         if (use < 1) use = 1;
         return (ctx->n_cu * use + 7) & ~7;
@@ -1684,8 +1685,8 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         if (ctx->S.n_shadow_lights <= 0) return RT_OK;
         if (beam) {
             hipLaunchKernelGGL(k_beam_setup, dim3(gsz(ctx->g_beam_setup, ctx->nb_beam_setup, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
-            hipLaunchKernelGGL(k_shadow_beam, dim3(gsz(ctx->g_beam, ctx->nb_beam, side)), block, 0, s_, ctx->S, lp, hb, bb, ctx->ctl);
-            hipLaunchKernelGGL(k_shadow_queue, dim3(gsz(ctx->g_queue, ctx->nb_queue, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, sg, bb, ctx->ctl);
+            hipLaunchKernelGGL(k_shadow_beam, dim3(gsz(ctx->g_beam, ctx->nb_beam, side == 1 ? 3 : side)), block, 0, s_, ctx->S, lp, hb, bb, ctx->ctl);
+            hipLaunchKernelGGL(k_shadow_queue, dim3(gsz(ctx->g_queue, ctx->nb_queue, side == 1 ? 3 : side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, sg, bb, ctx->ctl);
         } else {
             hipLaunchKernelGGL(k_shadow_setup, dim3(gsz(ctx->g_setup, ctx->nb_setup, side)), block, 0, s_, ctx->S, lp, hb, sg, ctx->ctl);
             if (fast) hipLaunchKernelGGL(k_shadow<true>, dim3(gsz(ctx->g_shadow, ctx->nb_shadow, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, sg, ctx->ctl);
@@ -1735,7 +1736,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         // level 0 (caller's stream) is submitted first: the host needs ~10 us per launch, and the long chain of the
         // deeper levels must not delay the submission of the frame's largest kernel
         if (int rc = shadows(0, st, ctx->q[0], ctx->hb, ctx->seg, ctx->beam, 1)) return rc;
-        hipLaunchKernelGGL(k_shade<RT_SHADE_LIGHTS>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 1)), block, 0, st, ctx->S, lp, ctx->q[0], ctx->q[1], ctx->hb, ctx->ctl, fb0,
+        hipLaunchKernelGGL(k_shade<RT_SHADE_LIGHTS>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 3)), block, 0, st, ctx->S, lp, ctx->q[0], ctx->q[1], ctx->hb, ctx->ctl, fb0,
                            ctx->beam.litbits, ctx->beam.pair_slot, ctx->beam.queue_n);
         // deeper levels (stream2): few, long rays - their waves ask for issue priority over the level-0 waves
         lp.prio = getenv("RT_AMD_NO_PRIO") ? 0 : 1;
