@@ -232,6 +232,34 @@ int rt_unit_prim_normals(int device, int kind, const double *params12, const dou
 int rt_unit_slab_mask(int device, const double *lo, const double *hi, int outside_hits_only, const double *origins,
                       const double *directions, int64_t n, uint8_t *mask_out, double *t_near_out);
 
+/*
+ * Tree build on the GPU.  Replaces BSPNode.build_bsp_tree (BSPNode.py:99-121) and its
+ * recursion build_bsp_tree_rec (BSPNode.py:54-97): the finite objects' enclosing corners
+ * (Object3D.get_enclosing_values) in list order go in, the tree comes out in the DFS pre-order layout of
+ * rt_scene_desc (node_lo/hi/right/first/count + leaf lists), bit-identical to the recursive host build:
+ * same float64 cut locations, same membership, same order inside every leaf.
+ *   small_corner / big_corner [n*3] float64 (host), root_lo / root_hi [3] or NULL (= min / max over the
+ *   corners, BSPNode.py:113-118), leaf_size = 10 and epsilon = util.EPSILON in the reference (BSPNode.py:67).
+ * leaf_prim holds POSITIONS into the caller's corner arrays.  The result stays in HBM until rt_bsp_fetch
+ * copies it into host arrays sized from rt_bsp_stats (any pointer may be NULL).
+ */
+typedef struct rt_bsp rt_bsp;
+typedef struct rt_bsp_stats {
+    double ms_total;       /* host wall clock of rt_bsp_build: uploads, kernels, per-level read-backs */
+    double ms_device;      /* HIP events around all kernels of the build on its stream */
+    int32_t n_nodes, n_leaf_refs, depth, launches;
+    int64_t ref_visits;    /* sum over the levels of the references classified there */
+    int64_t bytes_scratch; /* HBM taken during the build (freed on return, except the result) */
+} rt_bsp_stats;
+int rt_bsp_build(int device, int64_t n, const double *small_corner, const double *big_corner, const double *root_lo,
+                 const double *root_hi, int leaf_size, double epsilon, rt_bsp **out);
+int rt_bsp_stats_get(const rt_bsp *tree, rt_bsp_stats *stats);
+int rt_bsp_fetch(rt_bsp *tree, double *node_lo, double *node_hi, int32_t *node_right, int32_t *node_first,
+                 int32_t *node_count, int32_t *leaf_prim);
+int rt_bsp_destroy(rt_bsp *tree);
+/* Message of the last failure on `tree` (NULL: last rt_bsp_build failure of this thread). */
+const char *rt_bsp_last_error(const rt_bsp *tree);
+
 #ifdef __cplusplus
 }
 #endif

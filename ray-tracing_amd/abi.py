@@ -61,6 +61,16 @@ class Stats(C.Structure):
         return d
 
 
+class BspStats(C.Structure):
+    _fields_ = [
+        ("ms_total", C.c_double), ("ms_device", C.c_double), ("n_nodes", C.c_int32), ("n_leaf_refs", C.c_int32),
+        ("depth", C.c_int32), ("launches", C.c_int32), ("ref_visits", C.c_int64), ("bytes_scratch", C.c_int64),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 def render_params(width, height, sh_rays=None, rec_max=None, jitter=False, seed=0, rank=0, world=1, tile_w=0,
                   tile_h=0, flags=0):
     return RenderParams(int(width), int(height), RT_USE_SCENE_VALUE if sh_rays is None else int(sh_rays),

@@ -17,7 +17,8 @@ _LIB = None
 
 EXPORTS = ("rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_tile_pixels", "rt_tile_layout",
            "rt_render", "rt_render_device", "rt_sync_stats", "rt_trace", "rt_intersect", "rt_deinterleave_u8",
-           "rt_initial_rays", "rt_unit_prim_intersect", "rt_unit_prim_normals", "rt_unit_slab_mask")
+           "rt_initial_rays", "rt_unit_prim_intersect", "rt_unit_prim_normals", "rt_unit_slab_mask",
+           "rt_bsp_build", "rt_bsp_stats_get", "rt_bsp_fetch", "rt_bsp_destroy", "rt_bsp_last_error")
 
 
 class NativeError(RuntimeError):
@@ -57,6 +58,13 @@ def lib():
         L.rt_unit_prim_normals.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.rt_unit_slab_mask.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
                                         C.c_void_p, C.c_void_p]
+        L.rt_bsp_last_error.restype = C.c_char_p
+        L.rt_bsp_last_error.argtypes = [C.c_void_p]
+        L.rt_bsp_build.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                   C.c_double, C.POINTER(C.c_void_p)]
+        L.rt_bsp_stats_get.argtypes = [C.c_void_p, C.POINTER(abi.BspStats)]
+        L.rt_bsp_fetch.argtypes = [C.c_void_p] * 7
+        L.rt_bsp_destroy.argtypes = [C.c_void_p]
         if L.rt_abi_version() != abi.RT_AMD_ABI_VERSION:
             raise RuntimeError("librt_amd.so ABI version mismatch")
         _LIB = L
@@ -193,3 +201,37 @@ def slab_mask(origins, directions, bounds_min, bounds_max, outside_hits_only=Tru
     _check(lib().rt_unit_slab_mask(device, lo.ctypes.data, hi.ctypes.data, 1 if outside_hits_only else 0,
                                    o.ctypes.data, d.ctypes.data, o.shape[0], mask.ctypes.data, tn.ctypes.data))
     return mask.astype(bool)[:, None], tn[:, None]
+
+
+# -- tree build on the GPU (BSPNode.build_bsp_tree, BSPNode.py:54-121) ---------------------------
+def bsp_build(small_corner, big_corner, root_lo=None, root_hi=None, leaf_size=10, epsilon=1e-6, device=0):
+    """-> dict(lo (n,3), hi (n,3), right, first, count, leaf_prim (int32), stats).  The tree is built in HBM
+    by rt_bsp_build and copied back in the DFS pre-order layout of rt_scene_desc; leaf_prim holds
+    positions into the corner arrays."""
+    small, big = _f64(small_corner).reshape(-1, 3), _f64(big_corner).reshape(-1, 3)
+    if small.shape != big.shape:
+        raise ValueError("small_corner/big_corner must both be (N,3)")
+    rlo = None if root_lo is None else _f64(root_lo).reshape(3)
+    rhi = None if root_hi is None else _f64(root_hi).reshape(3)
+    h = C.c_void_p()
+    rc = lib().rt_bsp_build(int(device), small.shape[0], small.ctypes.data, big.ctypes.data,
+                            None if rlo is None else rlo.ctypes.data, None if rhi is None else rhi.ctypes.data,
+                            int(leaf_size), float(epsilon), C.byref(h))
+    if rc != abi.RT_OK:
+        msg = lib().rt_bsp_last_error(None)
+        raise NativeError(rc, msg.decode() if msg else "")
+    try:
+        st = abi.BspStats()
+        lib().rt_bsp_stats_get(h, C.byref(st))
+        n, r = st.n_nodes, st.n_leaf_refs
+        out = dict(lo=np.empty((n, 3)), hi=np.empty((n, 3)), right=np.empty(n, dtype=np.int32),
+                   first=np.empty(n, dtype=np.int32), count=np.empty(n, dtype=np.int32),
+                   leaf_prim=np.empty(r, dtype=np.int32))
+        rc = lib().rt_bsp_fetch(h, *[out[k].ctypes.data for k in ("lo", "hi", "right", "first", "count", "leaf_prim")])
+        if rc != abi.RT_OK:
+            msg = lib().rt_bsp_last_error(h)
+            raise NativeError(rc, msg.decode() if msg else "")
+        out["stats"] = st.as_dict()
+        return out
+    finally:
+        lib().rt_bsp_destroy(h)

@@ -16,19 +16,26 @@ from . import abi, native, scene_pack
 class Scene:
     """Parsed scene + tree + packed buffers (host side only)."""
 
-    def __init__(self, camera, settings, surfaces, materials, lights, bsp_tree=None):
+    def __init__(self, camera, settings, surfaces, materials, lights, bsp_tree=None, build="host", device=0):
+        """build = "host": the recursive NumPy restatement of BSPNode.build_bsp_tree (runs anywhere);
+        build = "device": the same tree built in HBM by rt_bsp_build (raises without a GPU)."""
         if bsp_tree is None:
             from BSPNode import BSPNode
-            bsp_tree = BSPNode.build_bsp_tree(surfaces)
+            if build == "device":
+                bsp_tree = BSPNode.build_bsp_tree_device(surfaces, device=device)
+            elif build == "host":
+                bsp_tree = BSPNode.build_bsp_tree(surfaces)
+            else:
+                raise ValueError("build must be 'host' or 'device'")
         self.camera, self.settings, self.surfaces = camera, settings, surfaces
         self.materials, self.lights, self.bsp_tree = materials, lights, bsp_tree
         self.packed = scene_pack.pack_scene(surfaces, materials, lights, camera, settings, bsp_tree)
 
     @classmethod
-    def from_file(cls, path):
+    def from_file(cls, path, build="host", device=0):
         from Parser import parse_scene_file
         camera, settings, _objs, surfaces, materials, lights = parse_scene_file(path)
-        return cls(camera, settings, surfaces, materials, lights)
+        return cls(camera, settings, surfaces, materials, lights, build=build, device=device)
 
 
 class Renderer:

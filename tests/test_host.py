@@ -107,12 +107,14 @@ def test_ctypes_structs_match_the_header(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rt_amd.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(rt_scene_desc),sizeof(rt_render_params),sizeof(rt_stats),offsetof(rt_scene_desc,cam_pos),'
-                   'offsetof(rt_scene_desc,leaf_prim),offsetof(rt_stats,ms_total));return 0;}\n')
+                   'offsetof(rt_scene_desc,leaf_prim),offsetof(rt_stats,ms_total));'
+                   'printf("%zu %zu\\n",sizeof(rt_bsp_stats),offsetof(rt_bsp_stats,ref_visits));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(abi.SceneDesc), ctypes.sizeof(abi.RenderParams), ctypes.sizeof(abi.Stats),
-            abi.SceneDesc.cam_pos.offset, abi.SceneDesc.leaf_prim.offset, abi.Stats.ms_total.offset]
+            abi.SceneDesc.cam_pos.offset, abi.SceneDesc.leaf_prim.offset, abi.Stats.ms_total.offset,
+            ctypes.sizeof(abi.BspStats), abi.BspStats.ref_visits.offset]
     assert got == want
 
 
@@ -134,6 +136,18 @@ def test_no_gpu_is_an_error_not_a_fallback():
     with pytest.raises(native.NativeError) as e:
         native.Context(load_scene("pool")["packed"])
     assert e.value.code == -2
+
+
+def test_tree_build_without_a_gpu_is_an_error_not_a_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(native.NativeError) as e:
+        native.bsp_build(np.zeros((4, 3)), np.ones((4, 3)))
+    assert e.value.code == -2
+    from BSPNode import BSPNode
+    with pytest.raises(native.NativeError):
+        BSPNode.build_bsp_tree_device(load_scene("pool")["surfaces"])
 
 
 def test_product_never_imports_the_oracle():
