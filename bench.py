@@ -35,31 +35,34 @@ F_SHADOW_SETUP, F_SHADE, F_RAY_SETUP, F_RAYGEN = 40, 50, 12, 25
 PEAK_FP32_VALU_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz
 
 
-def build_scene(workload):
+def build_scene(workload, ingest="native", device=0):
+    """ingest = "native": C++ tokenizer + GPU tree build (render.FastScene); "python": Parser objects +
+    recursive host build + scene_pack.  Both give bit-identical tables (tests/test_scene_native.py,
+    tests/test_gpu_build.py).  -> (scene, seconds spent on ingestion)"""
     import ray_tracing_amd  # noqa: F401
     import gen_scene
-    from ray_tracing_amd.render import Scene
-    if workload == "synth10k":
-        text = gen_scene.synth_spheres(100, 1234, 5, 5)
-    elif workload == "synth400":
-        text = gen_scene.synth_spheres(20, 1234, 5, 5)
-    elif workload == "synth1M":
-        text = gen_scene.synth_mixed(1000, 4321, 5, 10)           # BASELINE.json configs[4]: 1M spheres/boxes, R = 10
-    elif workload == "synth90k":
-        text = gen_scene.synth_mixed(300, 4321, 5, 10)
-    elif workload == "pool":
-        return Scene.from_file(os.path.join(ROOT, "tests", "golden", "scenes", "pool.txt"))
-    elif workload == "original":
-        return Scene.from_file(os.path.join(ROOT, "tests", "golden", "scenes", "original.txt"))
+    from ray_tracing_amd.render import FastScene, Scene
+    generated = {"synth10k": lambda: gen_scene.synth_spheres(100, 1234, 5, 5),
+                 "synth400": lambda: gen_scene.synth_spheres(20, 1234, 5, 5),
+                 "synth1M": lambda: gen_scene.synth_mixed(1000, 4321, 5, 10),    # BASELINE.json configs[4], R = 10
+                 "synth90k": lambda: gen_scene.synth_mixed(300, 4321, 5, 10)}
+    fixtures = {"pool": "pool.txt", "original": "original.txt"}
+    tmp = None
+    if workload in generated:
+        with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+            f.write(generated[workload]())
+            path = tmp = f.name
+    elif workload in fixtures:
+        path = os.path.join(ROOT, "tests", "golden", "scenes", fixtures[workload])
     else:
         raise SystemExit("unknown workload " + workload)
-    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
-        f.write(text)
-        path = f.name
     try:
-        return Scene.from_file(path)
+        t0 = time.perf_counter()
+        scene = FastScene.from_file(path, device=device) if ingest == "native" else Scene.from_file(path)
+        return scene, time.perf_counter() - t0
     finally:
-        os.unlink(path)
+        if tmp:
+            os.unlink(tmp)
 
 
 def algorithmic_flops(cnt, n_lights, n_planes):
@@ -85,6 +88,8 @@ def main():
     ap.add_argument("--sh-rays", type=int, default=None)
     ap.add_argument("--rec-max", type=int, default=None)
     ap.add_argument("--no-jitter", action="store_true")
+    ap.add_argument("--ingest", choices=("native", "python"), default="native",
+                    help="scene text -> tables -> tree: C++ tokenizer + GPU tree build, or Python objects + host build")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-div", type=int, default=4, help="CPU baseline renders (W/div)x(H/div)")
     args = ap.parse_args()
@@ -108,8 +113,10 @@ def main():
     from ray_tracing_amd import abi, native
     from ray_tracing_amd.render import gather_packed
 
-    scene = build_scene(args.workload)
+    scene, ingest_s = build_scene(args.workload, args.ingest, local_rank)
+    t_up = time.perf_counter()
     ctx = native.Context(scene.packed, device=local_rank)
+    upload_s = time.perf_counter() - t_up
     W = args.width or (1920 if world == 1 else 3840)
     H = args.height or (1080 if world == 1 else 2160)
     jitter = not args.no_jitter
@@ -229,6 +236,11 @@ def main():
         value = rays_per_frame * args.steps / elapsed / 1e6
         sh_used = args.sh_rays if args.sh_rays is not None else scene.settings.root_number_shadow_rays
         rec_used = args.rec_max if args.rec_max is not None else scene.settings.max_recursions
+        ingest_info = {"kind": args.ingest, "text_to_tables_and_tree_ms": round(ingest_s * 1e3, 1),
+                       "rt_create_ms": round(upload_s * 1e3, 1), "outside_timed_region": True}
+        if args.ingest == "native":
+            ingest_info.update(parse_ms=round(scene.timing["parse_ms"], 1), tree_ms=round(scene.timing["tree_ms"], 1),
+                               tree_device_ms=round(scene.timing["tree_device_ms"], 2))
         line = {
             "metric": "Mrays/s (rays handed to the nearest-hit query, whole job); frame time = ms_per_step",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -239,7 +251,8 @@ def main():
                 args.workload, W, H, sh_used, sh_used, rec_used, "on" if jitter else "off"),
                 "primitives": scene.packed.desc.n_spheres + scene.packed.desc.n_boxes + scene.packed.desc.n_planes,
                 "lights": scene.packed.desc.n_lights, "bsp_nodes": scene.packed.desc.n_nodes,
-                "rays_per_frame": int(rays_per_frame), "partition": "8x8 tiles interleaved over %d rank(s)" % world},
+                "rays_per_frame": int(rays_per_frame), "partition": "8x8 tiles interleaved over %d rank(s)" % world,
+                "ingest": ingest_info},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line), flush=True)

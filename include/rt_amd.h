@@ -260,6 +260,40 @@ int rt_bsp_destroy(rt_bsp *tree);
 /* Message of the last failure on `tree` (NULL: last rt_bsp_build failure of this thread). */
 const char *rt_bsp_last_error(const rt_bsp *tree);
 
+/*
+ * Scene ingestion without Python objects.  Replaces Parser.parse_scene_file
+ * (Parser.py:25-71) plus the flattening into rt_scene_desc: the scene text goes in, the SoA tables come out,
+ * bit-identical to what the Python path derives (same index rules: one counter for sph/pln/box and lgt lines
+ * from 1, Background at list position 0, materials sorted by index with the `set` line's background material
+ * first).  Errors (unknown line type, a token float() would refuse, too few numbers) name the line.
+ *   threads <= 0: RT_AMD_PARSE_THREADS or min(16, hardware threads); the text is cut at line ends.
+ * The tree is attached afterwards, either built on the GPU from the scene's own corner arrays
+ * (rt_scene_build_tree = rt_bsp_build + rt_bsp_fetch + position -> primitive-number mapping) or handed in
+ * (rt_scene_set_tree, leaf entries as positions in the finite-object order, as BSPNode keeps them).
+ * rt_scene_get_desc stays valid until rt_scene_free; pass it to rt_create.
+ */
+typedef struct rt_scene rt_scene;
+typedef struct rt_scene_info {
+    int64_t lines;        /* text lines read */
+    int64_t n_records;    /* non-empty, non-comment lines */
+    int64_t n_finite;     /* spheres + boxes = entries of the corner arrays */
+    int32_t threads, has_camera, has_settings, reserved;
+} rt_scene_info;
+int rt_scene_parse(const char *text, int64_t len, int threads, rt_scene **out);
+int rt_scene_parse_file(const char *path, int threads, rt_scene **out);
+const rt_scene_desc *rt_scene_get_desc(const rt_scene *scene);
+int rt_scene_get_info(const rt_scene *scene, rt_scene_info *info);
+/* Object3D.get_enclosing_values of the finite objects in list order (Sphere.py:135-139, Cube.py:209-213). */
+int rt_scene_corners(const rt_scene *scene, const double **small_corner, const double **big_corner, int64_t *n);
+/* Light.index per light and Material.index per material row (Parser.py:54-66). */
+int rt_scene_light_ids(const rt_scene *scene, const int32_t **light_ids, const int32_t **material_ids);
+int rt_scene_set_tree(rt_scene *scene, int32_t n_nodes, const double *node_lo, const double *node_hi,
+                      const int32_t *node_right, const int32_t *node_first, const int32_t *node_count,
+                      int32_t n_leaf_refs, const int32_t *leaf_positions);
+int rt_scene_build_tree(rt_scene *scene, int device, rt_bsp_stats *stats /* may be NULL */);
+void rt_scene_free(rt_scene *scene);
+const char *rt_scene_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,32 @@ class BspStats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class SceneInfo(C.Structure):
+    _fields_ = [
+        ("lines", C.c_int64), ("n_records", C.c_int64), ("n_finite", C.c_int64), ("threads", C.c_int32),
+        ("has_camera", C.c_int32), ("has_settings", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+
+
+# rt_scene_desc tables: name -> (count field, columns)
+SCENE_TABLES = {
+    "surf_kind": ("n_surfaces", 1), "surf_geom": ("n_surfaces", 1), "surf_mat": ("n_surfaces", 1),
+    "sph_center": ("n_spheres", 3), "sph_radius": ("n_spheres", 1), "sph_r2": ("n_spheres", 1), "sph_id": ("n_spheres", 1),
+    "box_center": ("n_boxes", 3), "box_scale": ("n_boxes", 1), "box_lo": ("n_boxes", 3), "box_hi": ("n_boxes", 3),
+    "box_id": ("n_boxes", 1),
+    "pln_normal": ("n_planes", 3), "pln_d": ("n_planes", 1), "pln_id": ("n_planes", 1),
+    "mat_kd": ("n_materials", 3), "mat_ks": ("n_materials", 3), "mat_kr": ("n_materials", 3),
+    "mat_phong": ("n_materials", 1), "mat_transparency": ("n_materials", 1),
+    "lgt_pos": ("n_lights", 3), "lgt_color": ("n_lights", 3), "lgt_spec": ("n_lights", 1), "lgt_shadow": ("n_lights", 1),
+    "lgt_radius": ("n_lights", 1),
+    "node_lo": ("n_nodes", 3), "node_hi": ("n_nodes", 3), "node_right": ("n_nodes", 1), "node_first": ("n_nodes", 1),
+    "node_count": ("n_nodes", 1), "leaf_prim": ("n_leaf_refs", 1),
+}
+
+
 def render_params(width, height, sh_rays=None, rec_max=None, jitter=False, seed=0, rank=0, world=1, tile_w=0,
                   tile_h=0, flags=0):
     return RenderParams(int(width), int(height), RT_USE_SCENE_VALUE if sh_rays is None else int(sh_rays),

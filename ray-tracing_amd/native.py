@@ -18,7 +18,9 @@ _LIB = None
 EXPORTS = ("rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_tile_pixels", "rt_tile_layout",
            "rt_render", "rt_render_device", "rt_sync_stats", "rt_trace", "rt_intersect", "rt_deinterleave_u8",
            "rt_initial_rays", "rt_unit_prim_intersect", "rt_unit_prim_normals", "rt_unit_slab_mask",
-           "rt_bsp_build", "rt_bsp_stats_get", "rt_bsp_fetch", "rt_bsp_destroy", "rt_bsp_last_error")
+           "rt_bsp_build", "rt_bsp_stats_get", "rt_bsp_fetch", "rt_bsp_destroy", "rt_bsp_last_error",
+           "rt_scene_parse", "rt_scene_parse_file", "rt_scene_get_desc", "rt_scene_get_info", "rt_scene_corners",
+           "rt_scene_light_ids", "rt_scene_set_tree", "rt_scene_build_tree", "rt_scene_free", "rt_scene_last_error")
 
 
 class NativeError(RuntimeError):
@@ -65,6 +67,20 @@ def lib():
         L.rt_bsp_stats_get.argtypes = [C.c_void_p, C.POINTER(abi.BspStats)]
         L.rt_bsp_fetch.argtypes = [C.c_void_p] * 7
         L.rt_bsp_destroy.argtypes = [C.c_void_p]
+        L.rt_scene_last_error.restype = C.c_char_p
+        L.rt_scene_parse.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
+        L.rt_scene_parse_file.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.rt_scene_get_desc.restype = C.POINTER(abi.SceneDesc)
+        L.rt_scene_get_desc.argtypes = [C.c_void_p]
+        L.rt_scene_get_info.argtypes = [C.c_void_p, C.POINTER(abi.SceneInfo)]
+        L.rt_scene_corners.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.POINTER(C.c_double)),
+                                       C.POINTER(C.c_int64)]
+        L.rt_scene_light_ids.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32))]
+        L.rt_scene_set_tree.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int32, C.c_void_p]
+        L.rt_scene_build_tree.argtypes = [C.c_void_p, C.c_int, C.POINTER(abi.BspStats)]
+        L.rt_scene_free.argtypes = [C.c_void_p]
+        L.rt_scene_free.restype = None
         if L.rt_abi_version() != abi.RT_AMD_ABI_VERSION:
             raise RuntimeError("librt_amd.so ABI version mismatch")
         _LIB = L
@@ -235,3 +251,90 @@ def bsp_build(small_corner, big_corner, root_lo=None, root_hi=None, leaf_size=10
         return out
     finally:
         lib().rt_bsp_destroy(h)
+
+
+# -- scene ingestion without Python objects (Parser.parse_scene_file, Parser.py:25-71) ------------
+class NativeScene:
+    """Scene tables made by rt_scene_parse / rt_scene_parse_file.  Quacks like scene_pack.PackedScene
+    (`desc`, `arrays`, `counts`), so native.Context(scene) and the oracle wrapper take it as is.  The tree is
+    attached by build_tree (GPU) or set_tree (a FlatTree of the host builder)."""
+
+    def __init__(self, text=None, path=None, threads=0):
+        self._h = C.c_void_p()
+        if (text is None) == (path is None):
+            raise ValueError("give either text or path")
+        if path is not None:
+            rc = lib().rt_scene_parse_file(os.fsencode(path), int(threads), C.byref(self._h))
+        else:
+            raw = text.encode() if isinstance(text, str) else bytes(text)
+            rc = lib().rt_scene_parse(raw, len(raw), int(threads), C.byref(self._h))
+        if rc != abi.RT_OK:
+            msg = (lib().rt_scene_last_error() or b"").decode()
+            if rc == -1:
+                raise ValueError(msg)           # the reference's parser raises ValueError for bad lines
+            raise NativeError(rc, msg)
+        self.desc = lib().rt_scene_get_desc(self._h).contents      # lives inside the native object
+        info = abi.SceneInfo()
+        lib().rt_scene_get_info(self._h, C.byref(info))
+        self.info = info.as_dict()
+        self.build_stats = None
+
+    def close(self):
+        if self._h:
+            lib().rt_scene_free(self._h)
+            self._h = C.c_void_p()
+            self.desc = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _view(self, ptr, rows, cols):
+        if rows == 0:
+            return np.zeros((0, cols) if cols > 1 else (0,), dtype=np.float64 if ptr._type_ is C.c_double else np.int32)
+        a = np.ctypeslib.as_array(ptr, shape=(rows * cols,))
+        return a.reshape(rows, cols) if cols > 1 else a
+
+    @property
+    def arrays(self):
+        """name -> NumPy view of the table (valid until close(); re-read after attaching a tree)."""
+        return {name: self._view(getattr(self.desc, name), getattr(self.desc, cnt), cols)
+                for name, (cnt, cols) in abi.SCENE_TABLES.items()}
+
+    @property
+    def counts(self):
+        d = self.desc
+        return dict(surfaces=d.n_surfaces, spheres=d.n_spheres, boxes=d.n_boxes, planes=d.n_planes,
+                    materials=d.n_materials, lights=d.n_lights, nodes=d.n_nodes, leaf_refs=d.n_leaf_refs)
+
+    def corners(self):
+        """Object3D.get_enclosing_values of the finite objects in list order -> (small (n,3), big (n,3)) views."""
+        ps, pb, n = C.POINTER(C.c_double)(), C.POINTER(C.c_double)(), C.c_int64()
+        lib().rt_scene_corners(self._h, C.byref(ps), C.byref(pb), C.byref(n))
+        return self._view(ps, n.value, 3), self._view(pb, n.value, 3)
+
+    def ids(self):
+        """(Light.index per light, Material.index per material row)."""
+        pl, pm = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+        lib().rt_scene_light_ids(self._h, C.byref(pl), C.byref(pm))
+        return self._view(pl, self.desc.n_lights, 1).copy(), self._view(pm, self.desc.n_materials, 1).copy()
+
+    def build_tree(self, device=0):
+        st = abi.BspStats()
+        rc = lib().rt_scene_build_tree(self._h, int(device), C.byref(st))
+        if rc != abi.RT_OK:
+            raise NativeError(rc, (lib().rt_scene_last_error() or b"").decode())
+        self.build_stats = st.as_dict()
+        return self.build_stats
+
+    def set_tree(self, flat):
+        """flat: FlatTree of BSPNode.build_bsp_tree (leaf_prim = positions in the finite-object order)."""
+        lo, hi = _f64(flat.lo), _f64(flat.hi)
+        right, first, count, leaf = (np.ascontiguousarray(a, dtype=np.int32)
+                                     for a in (flat.right, flat.first, flat.count, flat.leaf_prim))
+        rc = lib().rt_scene_set_tree(self._h, len(right), lo.ctypes.data, hi.ctypes.data, right.ctypes.data,
+                                     first.ctypes.data, count.ctypes.data, len(leaf), leaf.ctypes.data)
+        if rc != abi.RT_OK:
+            raise NativeError(rc, (lib().rt_scene_last_error() or b"").decode())

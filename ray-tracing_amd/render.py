@@ -38,6 +38,33 @@ class Scene:
         return cls(camera, settings, surfaces, materials, lights, build=build, device=device)
 
 
+class FastScene:
+    """Scene file -> tables -> tree with no Python object per surface: rt_scene_parse(_file) tokenizes the text
+    into the rt_scene_desc tables (bit-identical to Parser + scene_pack) and rt_scene_build_tree builds the
+    reference's BSP tree on the GPU.  Takes a million-line scene in a fraction of a second where the object
+    path needs half a minute.  Has the attributes Renderer and bench.py use (`packed`, `settings`)."""
+
+    class _Settings:
+        def __init__(self, desc):
+            self.background_color = list(desc.background)
+            self.root_number_shadow_rays = int(desc.sh_rays)
+            self.max_recursions = int(desc.rec_max)
+
+    def __init__(self, path=None, text=None, device=0, threads=0):
+        import time
+        t0 = time.perf_counter()
+        self.packed = native.NativeScene(text=text, path=path, threads=threads)
+        t1 = time.perf_counter()
+        self.build_stats = self.packed.build_tree(device)
+        t2 = time.perf_counter()
+        self.settings = FastScene._Settings(self.packed.desc)
+        self.timing = dict(parse_ms=(t1 - t0) * 1e3, tree_ms=(t2 - t1) * 1e3, tree_device_ms=self.build_stats["ms_device"])
+
+    @classmethod
+    def from_file(cls, path, device=0, threads=0):
+        return cls(path=path, device=device, threads=threads)
+
+
 class Renderer:
     def __init__(self, scene: Scene, device=0):
         self.scene = scene

@@ -50,9 +50,15 @@ def ray_tracing(rays_sources, rays_directions, surfaces, materials, lights, scen
 
 def main(argv=None):
     args = parse_args(argv)
-    camera, scene_settings, _objects, surfaces, materials, light_sources = parse_scene_file(args.scene_file)
-    bsp_tree = BSPNode.build_bsp_tree(surfaces=surfaces)
-    ctx = _context_for(surfaces, materials, light_sources, scene_settings, camera, bsp_tree)
+    if args.python_ingest:
+        # the reference's own sequence: objects, recursive tree, then the tables
+        camera, scene_settings, _objects, surfaces, materials, light_sources = parse_scene_file(args.scene_file)
+        bsp_tree = BSPNode.build_bsp_tree(surfaces=surfaces)
+        ctx = _context_for(surfaces, materials, light_sources, scene_settings, camera, bsp_tree)
+    else:
+        # same tables and same tree, made by the C++ tokenizer and the GPU tree build (render.FastScene)
+        from ray_tracing_amd.render import FastScene
+        ctx = native.Context(FastScene.from_file(args.scene_file).packed)
     # ray generation, tracing, clip(0,1) and the 8-bit quantisation are one fused GPU frame
     p = abi.render_params(args.width, args.height, sh_rays=args.shadow_rays, jitter=not args.no_jitter,
                           seed=args.seed)

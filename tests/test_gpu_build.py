@@ -145,3 +145,47 @@ def test_frame_from_a_device_built_scene_matches_the_reference_frame():
         r.close()
     assert np.abs(out["rgb8"].astype(int) - g["rgb8_q4fix"].astype(int)).max() <= 1
     assert abi.RT_OK == 0
+
+
+# ------------------------------------------------------------------ text -> tables -> tree -> frame, no Python objects
+@pytest.mark.parametrize("tag", ["pool", "original", "small", "synth400"])
+def test_fast_scene_has_the_tables_and_tree_of_the_object_path(tag):
+    from ray_tracing_amd.render import FastScene
+    from test_scene_native import assert_same_tables
+    sc = load_scene(tag)
+    fs = FastScene.from_file(scene_path(tag))
+    assert_same_tables(fs.packed, sc["packed"])
+    assert fs.build_stats["n_nodes"] == sc["packed"].desc.n_nodes
+    assert fs.settings.root_number_shadow_rays == sc["settings"].root_number_shadow_rays
+    assert fs.settings.max_recursions == sc["settings"].max_recursions
+
+
+def test_fast_scene_on_a_mixed_lattice(tmp_path):
+    import gen_scene
+    from ray_tracing_amd.render import FastScene
+    from test_scene_native import assert_same_tables, python_path
+    p = tmp_path / "mixed.txt"
+    p.write_text(gen_scene.synth_mixed(60, 99, 3, 4))
+    py = python_path(str(p))
+    fs = FastScene.from_file(str(p))
+    assert_same_tables(fs.packed, py["packed"])
+    a = native.Context(fs.packed)
+    b = native.Context(py["packed"])
+    try:
+        prm = abi.render_params(160, 90, jitter=True, seed=5)
+        ra, rb = a.render(prm), b.render(prm)
+    finally:
+        a.close()
+        b.close()
+    assert np.array_equal(ra["ids"], rb["ids"]) and np.array_equal(ra["rgb8"], rb["rgb8"])
+
+
+def test_main_writes_the_same_image_with_either_ingestion(tmp_path):
+    import ray_tracer
+    from PIL import Image
+    a, b = str(tmp_path / "a.png"), str(tmp_path / "b.png")
+    common = [scene_path("pool"), None, "--width", "96", "--height", "54", "--no-jitter", "--shadow-rays", "2"]
+    ray_tracer.main([common[0], a] + common[2:])
+    ray_tracer.main([common[0], b] + common[2:] + ["--python-ingest"])
+    ia, ib = np.asarray(Image.open(a)), np.asarray(Image.open(b))
+    assert ia.shape == (54, 96, 3) and np.array_equal(ia, ib) and ia.max() > 0

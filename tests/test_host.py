@@ -94,8 +94,9 @@ def test_tile_layout_partitions_every_pixel_once():
 def test_library_exports_every_declared_symbol():
     with open(os.path.join(ROOT, "include", "rt_amd.h")) as f:
         header = f.read()
-    declared = set(re.findall(r"^(?:int|int64_t|const char \*)\s*\*?\s*(rt_[a-z0-9_]+)\s*\(", header, flags=re.M))
-    assert {"rt_create", "rt_render", "rt_intersect", "rt_trace", "rt_unit_prim_intersect"} <= declared
+    declared = set(re.findall(r"^(?:int|int64_t|void|const char \*|const rt_scene_desc \*)\s*\*?\s*(rt_[a-z0-9_]+)\s*\(", header, flags=re.M))
+    assert {"rt_create", "rt_render", "rt_intersect", "rt_trace", "rt_unit_prim_intersect", "rt_bsp_build",
+            "rt_scene_parse", "rt_scene_get_desc", "rt_scene_free"} <= declared
     lib = native.lib()
     for name in declared:
         assert hasattr(lib, name), name
