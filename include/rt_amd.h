@@ -181,6 +181,16 @@ int rt_tile_layout(const rt_render_params *p, int64_t *pixel_index /* [rt_tile_p
 int rt_render(rt_ctx *ctx, const rt_render_params *p, float *rgb_out, uint8_t *rgb8_out, int32_t *ids_out,
               rt_stats *stats);
 
+/*
+ * Mean of `frames` stochastic frames: the frames rt_render gives for seed, seed+1, ...,
+ * seed+frames-1, each clipped to [0,1] (ray_tracer.py:30), summed in float64 on the device and divided by `frames`
+ * before the float32 / uint8 outputs are written (util.py:98 for the quantisation).  The reference renders one frame
+ * per run; this is the accumulation its soft shadows need to converge (and what the PSNR parity check averages).
+ * stats: ray counters and ms_total summed over the frames.  Host buffers, blocking, either output may be NULL.
+ */
+int rt_render_mean(rt_ctx *ctx, const rt_render_params *p, int32_t frames, float *rgb_out, uint8_t *rgb8_out,
+                   rt_stats *stats);
+
 /* Same, outputs are DEVICE pointers on ctx's device (any may be NULL) and the
  * work is only enqueued on `stream` (a hipStream_t, NULL = the context's own
  * stream); nothing is synchronised.  Used by the bench and the multi-GPU gather. */

@@ -1034,6 +1034,22 @@ __global__ void __launch_bounds__(RT_BLOCK) k_resolve(const double *fb, const do
     }
 }
 
+// mean of K clipped frames: acc (+)= clip(frame); the last frame divides and quantises like k_resolve
+__global__ void __launch_bounds__(RT_BLOCK) k_accumulate(const double *fb, const double *fb0, double *acc, uint64_t n_values, int first,
+                                                         double frames_if_last, float *rgb, uint8_t *rgb8) {
+    for (uint64_t k = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x; k < n_values; k += (uint64_t)gridDim.x * RT_BLOCK) {
+        double v = fb0[k] + fb[k];
+        double c = v < 0 ? 0 : (v > 1 ? 1 : v);
+        double a = first ? c : acc[k] + c;
+        acc[k] = a;
+        if (frames_if_last > 0) {
+            double m = a / frames_if_last;
+            if (rgb) rgb[k] = (float)m;
+            if (rgb8) rgb8[k] = isnan(m) ? (uint8_t)0 : (uint8_t)(m * 255);
+        }
+    }
+}
+
 template <bool FAST>
 __global__ void __launch_bounds__(RT_BLOCK) k_intersect_only(DScene S, FastScene F, const double *o, const double *d,
                                                              uint64_t n, double *pts, int64_t *ids) {
@@ -1129,6 +1145,8 @@ struct rt_ctx {
     SegBuf seg1{};
     BeamBuf beam1{};
     double *fb = nullptr, *fb0 = nullptr;   // see k_resolve
+    double *acc = nullptr;                  // rt_render_mean: sum of the clipped frames
+    uint64_t acc_slots = 0;
     bool two_sets = false;                  // hb1 / seg1 / beam1 are separate allocations
     hipStream_t stream2 = nullptr;          // the deeper levels of an overlapped frame
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -1491,6 +1509,7 @@ extern "C" int rt_destroy(rt_ctx *ctx) {
     free_frame(ctx);
     for (void *p : ctx->scene_allocs) (void)hipFree(p);
     if (ctx->ctl) (void)hipFree(ctx->ctl);
+    if (ctx->acc) (void)hipFree(ctx->acc);
     if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -1928,6 +1947,64 @@ extern "C" int rt_render(rt_ctx *ctx, const rt_render_params *p, float *rgb_out,
         if (ids_out) TRY_R(hipMemcpy(ids_out, d_ids, g.out_slots * sizeof(int32_t), hipMemcpyDeviceToHost));
     }
 #undef TRY_R
+    cleanup();
+    return rc;
+}
+
+extern "C" int rt_render_mean(rt_ctx *ctx, const rt_render_params *p, int32_t frames, float *rgb_out, uint8_t *rgb8_out,
+                              rt_stats *stats) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (frames < 1 || frames > 65536) return fail(ctx, RT_ERR_INVALID_ARG, "frames must be 1..65536");
+    TileGeom g;
+    std::string why;
+    if (int rc = tile_geom(p, g, why)) return fail(ctx, rc, why);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->acc_slots < g.out_slots) {
+        if (ctx->acc) (void)hipFree(ctx->acc);
+        ctx->acc = nullptr;
+        ctx->acc_slots = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->acc, g.out_slots * 3 * sizeof(double)));
+        ctx->acc_slots = g.out_slots;
+    }
+    float *d_rgb = nullptr;
+    uint8_t *d_rgb8 = nullptr;
+    int rc = RT_OK;
+    auto cleanup = [&]() {
+        if (d_rgb) (void)hipFree(d_rgb);
+        if (d_rgb8) (void)hipFree(d_rgb8);
+    };
+#define TRY_M(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+    if (rgb_out) TRY_M(hipMalloc((void **)&d_rgb, g.out_slots * 3 * sizeof(float)));
+    if (rgb8_out) TRY_M(hipMalloc((void **)&d_rgb8, g.out_slots * 3));
+    rt_stats sum;
+    memset(&sum, 0, sizeof(sum));
+    for (int32_t k = 0; k < frames && rc == RT_OK; ++k) {
+        rt_render_params q = *p;
+        q.seed = p->seed + (uint32_t)k;                       // frame k of the mean = the frame rt_render gives for seed + k
+        rt_stats st;
+        for (int attempt = 0; attempt < 6; ++attempt) {
+            rc = rt_render_device(ctx, &q, nullptr, nullptr, nullptr, nullptr);
+            if (rc != RT_OK) break;
+            rc = rt_sync_stats(ctx, &st);
+            if (rc != RT_ERR_QUEUE_OVERFLOW) break;
+        }
+        if (rc != RT_OK) break;
+        const bool last = k + 1 == frames;
+        hipLaunchKernelGGL(k_accumulate, dim3(ctx->grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->fb, ctx->fb0, ctx->acc,
+                           g.out_slots * 3, k == 0 ? 1 : 0, last ? (double)frames : 0.0, d_rgb, d_rgb8);
+        sum.primary_rays += st.primary_rays; sum.shadow_rays += st.shadow_rays; sum.reflect_rays += st.reflect_rays;
+        sum.transmit_rays += st.transmit_rays; sum.hits += st.hits; sum.ms_total += st.ms_total;
+        if (st.levels > sum.levels) sum.levels = st.levels;
+        if (st.max_queue > sum.max_queue) sum.max_queue = st.max_queue;
+    }
+    if (rc == RT_OK) {
+        TRY_M(hipStreamSynchronize(ctx->stream));
+        TRY_M(hipGetLastError());
+        if (rgb_out) TRY_M(hipMemcpy(rgb_out, d_rgb, g.out_slots * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        if (rgb8_out) TRY_M(hipMemcpy(rgb8_out, d_rgb8, g.out_slots * 3, hipMemcpyDeviceToHost));
+        if (stats) *stats = sum;
+    }
+#undef TRY_M
     cleanup();
     return rc;
 }

@@ -23,6 +23,8 @@ def parse_args(argv=None):
     parser.add_argument('--seed', type=int, default=0, help='seed of the soft-shadow jitter hash')
     parser.add_argument('--no-jitter', action='store_true', help='deterministic shadows (jitter forced to 0)')
     parser.add_argument('--shadow-rays', type=int, default=None, help='override root_number_shadow_rays')
+    parser.add_argument('--frames', type=int, default=1,
+                        help='average this many stochastic frames (seeds seed, seed+1, ...) on the GPU')
     parser.add_argument('--python-ingest', action='store_true',
                         help='build the scene through Python objects and the recursive host tree build '
                              '(default: C++ tokenizer + GPU tree build, identical tables)')

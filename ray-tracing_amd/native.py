@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_PKG, "csrc", "librt_amd.so")
 _LIB = None
 
 EXPORTS = ("rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_tile_pixels", "rt_tile_layout",
-           "rt_render", "rt_render_device", "rt_sync_stats", "rt_trace", "rt_intersect", "rt_deinterleave_u8",
+           "rt_render", "rt_render_mean", "rt_render_device", "rt_sync_stats", "rt_trace", "rt_intersect", "rt_deinterleave_u8",
            "rt_initial_rays", "rt_unit_prim_intersect", "rt_unit_prim_normals", "rt_unit_slab_mask",
            "rt_bsp_build", "rt_bsp_stats_get", "rt_bsp_fetch", "rt_bsp_destroy", "rt_bsp_last_error",
            "rt_scene_parse", "rt_scene_parse_file", "rt_scene_get_desc", "rt_scene_get_info", "rt_scene_corners",
@@ -44,6 +44,8 @@ def lib():
         L.rt_destroy.argtypes = [C.c_void_p]
         L.rt_render.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.POINTER(abi.Stats)]
+        L.rt_render_mean.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_int32, C.c_void_p, C.c_void_p,
+                                     C.POINTER(abi.Stats)]
         L.rt_render_device.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]
         L.rt_sync_stats.argtypes = [C.c_void_p, C.POINTER(abi.Stats)]
@@ -147,6 +149,17 @@ class Context:
         _check(lib().rt_render(self._h, C.byref(params), rgb.ctypes.data if want_rgb else None, rgb8.ctypes.data,
                                ids.ctypes.data if want_ids else None, C.byref(st)), self._h)
         return dict(rgb=rgb, rgb8=rgb8, ids=ids, stats=st.as_dict())
+
+    def render_mean(self, params, frames, want_rgb=True):
+        """Mean of the clipped frames for seed .. seed+frames-1, accumulated on the device (rt_render_mean):
+        dict(rgb float32 (n,3), rgb8 uint8 (n,3), stats summed over the frames)."""
+        n = tile_pixels(params)
+        rgb = np.empty((n, 3), dtype=np.float32) if want_rgb else None
+        rgb8 = np.empty((n, 3), dtype=np.uint8)
+        st = abi.Stats()
+        _check(lib().rt_render_mean(self._h, C.byref(params), int(frames), rgb.ctypes.data if want_rgb else None,
+                                    rgb8.ctypes.data, C.byref(st)), self._h)
+        return dict(rgb=rgb, rgb8=rgb8, stats=st.as_dict())
 
     def render_device(self, params, d_rgb=0, d_rgb8=0, d_ids=0, stream=0):
         """Enqueue a frame; outputs are raw device pointers (ints, 0 = not wanted); returns immediately."""

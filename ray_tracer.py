@@ -62,7 +62,10 @@ def main(argv=None):
     # ray generation, tracing, clip(0,1) and the 8-bit quantisation are one fused GPU frame
     p = abi.render_params(args.width, args.height, sh_rays=args.shadow_rays, jitter=not args.no_jitter,
                           seed=args.seed)
-    out = ctx.render(p, want_rgb=False, want_ids=False)
+    if args.frames > 1:
+        out = ctx.render_mean(p, args.frames, want_rgb=False)
+    else:
+        out = ctx.render(p, want_rgb=False, want_ids=False)
     save_image(image_array=out["rgb8"], path=args.output_image, height=args.height, width=args.width)
     st = out["stats"]
     print("%dx%d: %.2f ms on the GPU, %d rays (%.1f Mrays/s)" % (args.width, args.height, st["ms_total"], st["rays"],

@@ -156,6 +156,42 @@ def test_soft_shadow_psnr_vs_reference_mean(gpu_ctx, name, sh):
     assert psnr >= 40.0, psnr
 
 
+def test_mean_of_frames_on_the_device_equals_the_mean_of_single_frames(gpu_ctx):
+    """rt_render_mean = the frames rt_render gives for seed .. seed+K-1, clipped, averaged (float64 on the device)."""
+    w, h, K = 160, 90, 7
+    ctx = gpu_ctx("pool")
+    kw = dict(sh_rays=3, rec_max=4, jitter=True)
+    acc = np.zeros((h * w, 3))
+    rays = 0
+    for k in range(K):
+        one = ctx.render(abi.render_params(w, h, seed=900 + k, **kw), want_ids=False)
+        acc += one["rgb"].astype(np.float64)
+        rays += one["stats"]["rays"]
+    out = ctx.render_mean(abi.render_params(w, h, seed=900, **kw), K)
+    assert np.abs(out["rgb"].astype(np.float64) - acc / K).max() < 1e-6      # float32 outputs on both sides
+    assert np.abs(out["rgb8"].astype(int) - np.floor(acc / K * 255).astype(int)).max() <= 1
+    assert out["stats"]["rays"] == rays
+    # K = 1 is rt_render itself, bit for bit; a rank's tiles average like the whole frame
+    single = ctx.render(abi.render_params(w, h, seed=900, **kw), want_ids=False)
+    m1 = ctx.render_mean(abi.render_params(w, h, seed=900, **kw), 1)
+    assert np.array_equal(m1["rgb"], single["rgb"]) and np.array_equal(m1["rgb8"], single["rgb8"])
+    p = abi.render_params(w, h, seed=900, rank=1, world=3, **kw)
+    part = ctx.render_mean(p, K)
+    pix = native.tile_layout(p)
+    ok = pix >= 0
+    assert np.array_equal(part["rgb8"][ok], out["rgb8"][pix[ok]])
+    with pytest.raises(native.NativeError):
+        ctx.render_mean(abi.render_params(w, h, **kw), 0)
+
+
+def test_mean_mode_psnr_vs_reference_mean(gpu_ctx):
+    g, meta = golden("stoch_pool_192x108_s2_mean32")
+    w, h = meta["width"], meta["height"]
+    out = gpu_ctx("pool").render_mean(abi.render_params(w, h, sh_rays=2, rec_max=meta["rec_max"], jitter=True, seed=77), 64)
+    mse = np.mean((out["rgb"].reshape(h, w, 3).astype(np.float64) - g["mean_rgb"].astype(np.float64)) ** 2)
+    assert 10 * np.log10(1.0 / mse) >= 40.0
+
+
 # ------------------------------------------------------------------ tiles / multi-GPU layout on one GPU
 def test_tile_partition_reassembles_bit_identical(gpu_ctx):
     w, h, world = 100, 52, 4
