@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_load_rays(const double *o, const d
 template <bool FAST, bool GEN>
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) k_intersect(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb,
                                                         FrameCtl *ctl, double *fb, int32_t *ids_out, GenParams gp, uint32_t *beam_counters,
-                                                        double *fb_side) {
+                                                        double *fb_side, double *fb_side2) {
     extern __shared__ uint2 lds_stack[];
     uint2 *stk = lds_stack + threadIdx.x;
     if (ctl->overflow) return;                    // a queue overflowed earlier in this frame: the frame is void
@@ -292,6 +292,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
             if (zs != RT_INVALID_SLOT) {
                 if (!active) { fb[3ull * zs] = 0.0; fb[3ull * zs + 1] = 0.0; fb[3ull * zs + 2] = 0.0; }
                 if (fb_side) { fb_side[3ull * zs] = 0.0; fb_side[3ull * zs + 1] = 0.0; fb_side[3ull * zs + 2] = 0.0; }
+                if (fb_side2) { fb_side2[3ull * zs] = 0.0; fb_side2[3ull * zs + 1] = 0.0; fb_side2[3ull * zs + 2] = 0.0; }
             }
         } else {
             slot = active ? q.slot[k] : RT_INVALID_SLOT;
@@ -1025,9 +1026,12 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, LevelParams lp, Ra
 // clip(0,1) (ray_tracer.py:30) and save_image's truncating quantisation (util.py:98)
 // fb0: what the level-0 rays add themselves (background of the misses, Phong term of the hits); fb: everything the
 // deeper levels add.  Two buffers keep the sum independent of how the two halves of the frame are scheduled.
-__global__ void __launch_bounds__(RT_BLOCK) k_resolve(const double *fb, const double *fb0, uint64_t n_values, float *rgb, uint8_t *rgb8) {
+// fbm: the background that the rays of levels 1.. add when they miss (k_intersect).  It is kept apart from fb because
+// the nearest-hit query of level L+1 runs beside the shading of level L: with one buffer the order of the float64
+// additions on a pixel would depend on the schedule.
+__global__ void __launch_bounds__(RT_BLOCK) k_resolve(const double *fb, const double *fb0, const double *fbm, uint64_t n_values, float *rgb, uint8_t *rgb8) {
     for (uint64_t k = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x; k < n_values; k += (uint64_t)gridDim.x * RT_BLOCK) {
-        double v = fb0[k] + fb[k];
+        double v = (fb0[k] + fb[k]) + fbm[k];
         double c = v < 0 ? 0 : (v > 1 ? 1 : v);
         if (rgb) rgb[k] = (float)c;
         if (rgb8) rgb8[k] = isnan(c) ? (uint8_t)0 : (uint8_t)(c * 255);
@@ -1035,10 +1039,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_resolve(const double *fb, const do
 }
 
 // mean of K clipped frames: acc (+)= clip(frame); the last frame divides and quantises like k_resolve
-__global__ void __launch_bounds__(RT_BLOCK) k_accumulate(const double *fb, const double *fb0, double *acc, uint64_t n_values, int first,
-                                                         double frames_if_last, float *rgb, uint8_t *rgb8) {
+__global__ void __launch_bounds__(RT_BLOCK) k_accumulate(const double *fb, const double *fb0, const double *fbm, double *acc, uint64_t n_values,
+                                                         int first, double frames_if_last, float *rgb, uint8_t *rgb8) {
     for (uint64_t k = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x; k < n_values; k += (uint64_t)gridDim.x * RT_BLOCK) {
-        double v = fb0[k] + fb[k];
+        double v = (fb0[k] + fb[k]) + fbm[k];
         double c = v < 0 ? 0 : (v > 1 ? 1 : v);
         double a = first ? c : acc[k] + c;
         acc[k] = a;
@@ -1138,13 +1142,17 @@ struct rt_ctx {
     // frame buffers
     uint64_t cap = 0;       // ray-queue capacity
     uint64_t fb_slots = 0;
+    uint64_t fb_slots_frame = 0;   // primary slots of the frame being enqueued
     double growth = 2.0;    // queue capacity = growth * primary slots
     std::vector<void *> frame_allocs;
-    RayQ q[3]{};            // level 0 -> q[0]; level k >= 1 -> q[1 + (k - 1) % 2]
-    HitBuf hb{}, hb1{};     // level 0 / deeper levels (so are seg, beam and seg1, beam1)
-    SegBuf seg1{};
-    BeamBuf beam1{};
-    double *fb = nullptr, *fb0 = nullptr;   // see k_resolve
+    RayQ q[4]{};            // level 0 -> q[0]; level k >= 1 -> q[1 + (k - 1) % 2] (% 3 when the deeper levels are pipelined)
+    HitBuf hb{}, hb1{}, hb2{};   // level 0 / deeper levels, odd / deeper levels, even (so are seg*, beam*)
+    SegBuf seg1{}, seg2{};
+    BeamBuf beam1{}, beam2{};
+    double *fb = nullptr, *fb0 = nullptr, *fbm = nullptr;   // see k_resolve
+    bool three_sets = false;                // hb2 / seg2 / beam2 are separate allocations: levels 1.. can be pipelined
+    hipStream_t stream3 = nullptr;          // soft shadows + Phong of levels 1.. in a pipelined frame
+    std::vector<hipEvent_t> ev_hit, ev_lit; // per level: nearest hits known / shading added
     double *acc = nullptr;                  // rt_render_mean: sum of the clipped frames
     uint64_t acc_slots = 0;
     bool two_sets = false;                  // hb1 / seg1 / beam1 are separate allocations
@@ -1263,6 +1271,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
     HIP_C(hipEventCreate(&ctx->ev1));
     // (a high-priority stream here hung the GPU under the persistent level-0 kernels; wave priority is set in the kernels instead)
     HIP_C(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    HIP_C(hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
     HIP_C(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     HIP_C(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     HIP_C(hipMalloc((void **)&ctx->ctl, sizeof(FrameCtl)));
@@ -1499,6 +1508,7 @@ static void free_frame(rt_ctx *ctx) {
     ctx->cap = 0;
     ctx->fb_slots = 0;
     ctx->fb = nullptr;
+    ctx->fbm = nullptr;
     ctx->fb0 = nullptr;
 }
 
@@ -1516,7 +1526,10 @@ extern "C" int rt_destroy(rt_ctx *ctx) {
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    for (hipEvent_t e : ctx->ev_hit) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ev_lit) (void)hipEventDestroy(e);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RT_OK;
@@ -1540,7 +1553,7 @@ static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
     free_frame(ctx);
     uint64_t cap = want_cap;
 #define TRY_A(expr) do { int rc_ = (expr); if (rc_ != RT_OK) { free_frame(ctx); return rc_; } } while (0)
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 4; ++i) {
         RayQ &q = ctx->q[i];
         TRY_A(dalloc(ctx, &q.ox, cap)); TRY_A(dalloc(ctx, &q.oy, cap)); TRY_A(dalloc(ctx, &q.oz, cap));
         TRY_A(dalloc(ctx, &q.dx, cap)); TRY_A(dalloc(ctx, &q.dy, cap)); TRY_A(dalloc(ctx, &q.dz, cap));
@@ -1550,27 +1563,31 @@ static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
     uint64_t nlit = cap * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1);
     ctx->beam_queue_cap = (uint32_t)(cap < 0x7fffffffull ? cap : 0x7fffffffull);
     ctx->two_sets = true;
-    for (int set = 0; set < 2; ++set) {          // level 0 / deeper levels: the two halves of an overlapped frame
-        if (set == 1) {
-            // the second set is a speed-up only: without the memory for it the levels share one set and run in sequence
+    ctx->three_sets = true;
+    for (int set = 0; set < 3; ++set) {          // level 0 / deeper levels (odd, even): the parts of an overlapped frame
+        if (set >= 1) {
+            // the second and third set are speed-ups only: without the memory for them levels share a set and run in sequence
             size_t free_b = 0, total_b = 0;
             const uint64_t need_b = cap * 40 + nlit * (4 + 72 + 16 * RT_PAIR_UNITS + 8 * (RT_BLOCK / 64) + 12) + (uint64_t)ctx->beam_queue_cap * 8;
-            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (uint64_t)free_b < need_b + need_b / 8 + slots * 24 || getenv("RT_AMD_ONE_SET")) {
-                ctx->hb1 = ctx->hb; ctx->seg1 = ctx->seg; ctx->beam1 = ctx->beam;
-                ctx->two_sets = false;
+            const char *lim = getenv("RT_AMD_SETS");      // 1, 2 or 3 (diagnostic)
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (uint64_t)free_b < need_b + need_b / 8 + slots * 48 || getenv("RT_AMD_ONE_SET") ||
+                (lim && atoi(lim) <= set)) {
+                if (set == 1) { ctx->hb1 = ctx->hb; ctx->seg1 = ctx->seg; ctx->beam1 = ctx->beam; ctx->two_sets = false; }
+                ctx->hb2 = ctx->hb1; ctx->seg2 = ctx->seg1; ctx->beam2 = ctx->beam1;
+                ctx->three_sets = false;
                 break;
             }
         }
-        HitBuf &hb = set ? ctx->hb1 : ctx->hb;
+        HitBuf &hb = set == 0 ? ctx->hb : (set == 1 ? ctx->hb1 : ctx->hb2);
         TRY_A(dalloc(ctx, &hb.px, cap)); TRY_A(dalloc(ctx, &hb.py, cap)); TRY_A(dalloc(ctx, &hb.pz, cap));
         TRY_A(dalloc(ctx, &hb.id, cap)); TRY_A(dalloc(ctx, &hb.list, cap));
         TRY_A(dalloc(ctx, &hb.lit, nlit));
         HIP_TRY(ctx, hipMemsetAsync(hb.lit, 0, nlit * sizeof(uint32_t), ctx->stream));
-        SegBuf &sg = set ? ctx->seg1 : ctx->seg;
+        SegBuf &sg = set == 0 ? ctx->seg : (set == 1 ? ctx->seg1 : ctx->seg2);
         TRY_A(dalloc(ctx, &sg.ux, nlit)); TRY_A(dalloc(ctx, &sg.uy, nlit)); TRY_A(dalloc(ctx, &sg.uz, nlit));
         TRY_A(dalloc(ctx, &sg.rx, nlit)); TRY_A(dalloc(ctx, &sg.ry, nlit)); TRY_A(dalloc(ctx, &sg.rz, nlit));
         TRY_A(dalloc(ctx, &sg.cx, nlit)); TRY_A(dalloc(ctx, &sg.cy, nlit)); TRY_A(dalloc(ctx, &sg.cz, nlit));
-        BeamBuf &bb = set ? ctx->beam1 : ctx->beam;
+        BeamBuf &bb = set == 0 ? ctx->beam : (set == 1 ? ctx->beam1 : ctx->beam2);
         TRY_A(dalloc(ctx, &bb.rec, (nlit + RT_BLOCK) * RT_PAIR_UNITS));   // + one chunk of slack: staging reads whole chunks
         TRY_A(dalloc(ctx, &bb.queue, (uint64_t)ctx->beam_queue_cap)); TRY_A(dalloc(ctx, &bb.queue_n, 4));
         TRY_A(dalloc(ctx, &bb.litbits, (nlit + 1) * (RT_BLOCK / 64)));      // worst case one pair per chunk (s*s > RT_BLOCK / 2)
@@ -1581,6 +1598,7 @@ static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     TRY_A(dalloc(ctx, &ctx->fb0, slots * 3));
     TRY_A(dalloc(ctx, &ctx->fb, slots * 3));
+    TRY_A(dalloc(ctx, &ctx->fbm, slots * 3));
 #undef TRY_A
     ctx->cap = cap;
     ctx->fb_slots = slots;
@@ -1669,8 +1687,16 @@ static int prof_prepare(rt_ctx *ctx, int levels) {
 // and joins before the resolve.  Both sides use fixed grids; the level-0 side leaves one workgroup slot per CU to
 // the other.  Results do not depend on the schedule: the two sides add into different framebuffers.
 // gen != nullptr: queue 0 is empty, k_intersect(0) makes the camera rays itself
+//
+// Pipelined deeper levels (three buffer sets, rec >= 2): a level's nearest-hit query is a latency chain as long as its
+// longest ray, and so is its soft-shadow pass; run back to back they made the deeper levels the longer half of small
+// frames.  The children of level L only need its hits, so
+//     stream2 : spawn(0) -> hits(1) -> spawn(1) -> hits(2) -> ...                       [misses add into fbm]
+//     stream3 : for L = 1..rec, as soon as hits(L) are known: soft shadows(L) -> Phong(L) [adds into fb, in level order]
+// hits(L) reuses the buffer set and ray queue of level L-2 and waits for that level's shading.
+// fbm: where the rays of levels 1.. add the background when they miss (may be fb itself when nothing overlaps).
 static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, int32_t rec, int32_t *d_ids, hipStream_t st,
-                          double *fb0, const GenParams *gen) {
+                          double *fb0, const GenParams *gen, double *fbm) {
     LevelParams lp{};
     lp.sh_rays = sh; lp.jitter = p->jitter; lp.seed = p->seed; lp.cap = (uint32_t)ctx->cap; lp.flags = p->flags;
     dim3 block(RT_BLOCK);
@@ -1713,17 +1739,19 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         }
         return RT_OK;
     };
-    auto intersect = [&](int level, hipStream_t s_, RayQ &qc, HitBuf &hb, double *fbx, int side, BeamBuf &bb) {
+    auto intersect = [&](int level, hipStream_t s_, RayQ &qc, HitBuf &hb, double *fbx, int side_, BeamBuf &bb) {
         uint32_t *bc = beam ? bb.queue_n : nullptr;
         lp.level = level;
         lp.last_level = (level == rec) ? 1 : 0;
         static const GenParams none{};
         int32_t *ids = level == 0 ? d_ids : nullptr;
         if (level == 0 && gen) {
-            if (fast) hipLaunchKernelGGL((k_intersect<true, true>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, *gen, bc, fbx != ctx->fb ? ctx->fb : nullptr);
-            else hipLaunchKernelGGL((k_intersect<false, true>), dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, *gen, bc, fbx != ctx->fb ? ctx->fb : nullptr);
-        } else if (fast) hipLaunchKernelGGL((k_intersect<true, false>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, none, bc, nullptr);
-        else hipLaunchKernelGGL((k_intersect<false, false>), dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, none, bc, nullptr);
+            // the camera-ray pass also zeroes the other framebuffers of the frame
+            double *side = fbx != ctx->fb ? ctx->fb : nullptr, *side2 = (fbm != ctx->fb && fbm != fbx) ? fbm : nullptr;
+            if (fast) hipLaunchKernelGGL((k_intersect<true, true>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side_)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, *gen, bc, side, side2);
+            else hipLaunchKernelGGL((k_intersect<false, true>), dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, *gen, bc, side, side2);
+        } else if (fast) hipLaunchKernelGGL((k_intersect<true, false>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side_)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, none, bc, nullptr, nullptr);
+        else hipLaunchKernelGGL((k_intersect<false, false>), dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, none, bc, nullptr, nullptr);
     };
     auto queue_of = [&](int level) -> RayQ & { return level == 0 ? ctx->q[0] : ctx->q[1 + ((level - 1) & 1)]; };
 
@@ -1734,7 +1762,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
             BeamBuf &bb = level == 0 ? ctx->beam : ctx->beam1;
             const int e = 2 + 6 * level;
             PROF_MARK(e + 0);
-            intersect(level, st, qc, hb, level == 0 ? fb0 : ctx->fb, 0, bb);
+            intersect(level, st, qc, hb, level == 0 ? fb0 : fbm, 0, bb);
             PROF_MARK(e + 1);
             PROF_MARK(e + 2);
             if (int rc = shadows(level, st, qc, hb, level == 0 ? ctx->seg : ctx->seg1, bb, 0)) return rc;
@@ -1758,18 +1786,58 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         hipLaunchKernelGGL(k_shade<RT_SHADE_LIGHTS>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 3)), block, 0, st, ctx->S, lp, ctx->q[0], ctx->q[1], ctx->hb, ctx->ctl, fb0,
                            ctx->beam.litbits, ctx->beam.pair_slot, ctx->beam.queue_n);
         // deeper levels (stream2): few, long rays - their waves ask for issue priority over the level-0 waves
-        lp.prio = getenv("RT_AMD_NO_PRIO") ? 0 : 1;
+        // (in frames of many million pixels the level-0 side is the long one and the priority only slows it down)
+        lp.prio = getenv("RT_AMD_NO_PRIO") ? 0 : (getenv("RT_AMD_PRIO") || ctx->fb_slots_frame <= (4u << 20) ? 1 : 0);
         lp.level = 0; lp.last_level = 0;
         hipLaunchKernelGGL(k_shade<RT_SHADE_SPAWN>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s2_, ctx->S, lp, ctx->q[0], ctx->q[1], ctx->hb, ctx->ctl, ctx->fb,
                            ctx->beam.litbits, ctx->beam.pair_slot, ctx->beam.queue_n);
-        for (int level = 1; level <= rec; ++level) {
-            RayQ &qc = queue_of(level), &qn = queue_of(level + 1);
-            intersect(level, s2_, qc, ctx->hb1, ctx->fb, 2, ctx->beam1);
-            if (int rc = shadows(level, s2_, qc, ctx->hb1, ctx->seg1, ctx->beam1, 2)) return rc;
-            hipLaunchKernelGGL(k_shade<3>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s2_, ctx->S, lp, qc, qn, ctx->hb1, ctx->ctl, ctx->fb,
-                               ctx->beam1.litbits, ctx->beam1.pair_slot, ctx->beam1.queue_n);
+        static const bool no_pipe = getenv("RT_AMD_NO_PIPELINE") != nullptr;
+        if (ctx->three_sets && rec >= 2 && !no_pipe) {
+            hipStream_t s3_ = ctx->stream3;
+            while ((int)ctx->ev_hit.size() <= rec) {
+                hipEvent_t a, b;
+                HIP_TRY(ctx, hipEventCreateWithFlags(&a, hipEventDisableTiming));
+                ctx->ev_hit.push_back(a);
+                HIP_TRY(ctx, hipEventCreateWithFlags(&b, hipEventDisableTiming));
+                ctx->ev_lit.push_back(b);
+            }
+            auto pq = [&](int level) -> RayQ & { return ctx->q[1 + (level - 1) % 3]; };
+            for (int level = 1; level <= rec; ++level) {
+                const bool odd = (level & 1) != 0;
+                HitBuf &hb = odd ? ctx->hb1 : ctx->hb2;
+                SegBuf &sg = odd ? ctx->seg1 : ctx->seg2;
+                BeamBuf &bb = odd ? ctx->beam1 : ctx->beam2;
+                RayQ &qc = pq(level), &qn = pq(level + 1);
+                // set and queue of level - 2 are reused: its shading must be through
+                if (level >= 3) HIP_TRY(ctx, hipStreamWaitEvent(s2_, ctx->ev_lit[level - 2], 0));
+                intersect(level, s2_, qc, hb, fbm, 2, bb);
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_hit[level], s2_));
+                // the chain of nearest-hit queries is the critical one: its next link is submitted first
+                if (level < rec)
+                    hipLaunchKernelGGL(k_shade<RT_SHADE_SPAWN>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s2_, ctx->S, lp, qc, qn, hb, ctx->ctl, ctx->fb,
+                                       bb.litbits, bb.pair_slot, bb.queue_n);
+                HIP_TRY(ctx, hipStreamWaitEvent(s3_, ctx->ev_hit[level], 0));
+                if (int rc = shadows(level, s3_, qc, hb, sg, bb, 2)) return rc;
+                if (level < rec)
+                    hipLaunchKernelGGL(k_shade<RT_SHADE_LIGHTS>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s3_, ctx->S, lp, qc, qn, hb, ctx->ctl, ctx->fb,
+                                       bb.litbits, bb.pair_slot, bb.queue_n);
+                else      // last level: no children, the would-be children's background is added with the Phong term
+                    hipLaunchKernelGGL(k_shade<3>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s3_, ctx->S, lp, qc, qn, hb, ctx->ctl, ctx->fb,
+                                       bb.litbits, bb.pair_slot, bb.queue_n);
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_lit[level], s3_));
+            }
+            lp.prio = 0;
+            HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_lit[rec], 0));      // stream3 is in level order: the last one covers all
+        } else {
+            for (int level = 1; level <= rec; ++level) {
+                RayQ &qc = queue_of(level), &qn = queue_of(level + 1);
+                intersect(level, s2_, qc, ctx->hb1, fbm, 2, ctx->beam1);
+                if (int rc = shadows(level, s2_, qc, ctx->hb1, ctx->seg1, ctx->beam1, 2)) return rc;
+                hipLaunchKernelGGL(k_shade<3>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s2_, ctx->S, lp, qc, qn, ctx->hb1, ctx->ctl, ctx->fb,
+                                   ctx->beam1.litbits, ctx->beam1.pair_slot, ctx->beam1.queue_n);
+            }
+            lp.prio = 0;
         }
-        lp.prio = 0;
         HIP_TRY(ctx, hipEventRecord(ctx->ev_join, s2_));
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
     }
@@ -1789,6 +1857,7 @@ extern "C" int rt_render_device(rt_ctx *ctx, const rt_render_params *p, float *d
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     uint64_t need = g.slots > g.out_slots ? g.slots : g.out_slots;
     if (int rc = ensure_frame(ctx, need)) return rc;
+    ctx->fb_slots_frame = g.slots;
 
     GenParams gp{};
     const rt_scene_desc &s = ctx->host;
@@ -1813,6 +1882,7 @@ extern "C" int rt_render_device(rt_ctx *ctx, const rt_render_params *p, float *d
     if (prof || rec < 0) {      // otherwise k_intersect(0) initialises both framebuffers while it makes the camera rays
         HIP_TRY(ctx, hipMemsetAsync(ctx->fb, 0, g.out_slots * 3 * sizeof(double), st));
         HIP_TRY(ctx, hipMemsetAsync(ctx->fb0, 0, g.out_slots * 3 * sizeof(double), st));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->fbm, 0, g.out_slots * 3 * sizeof(double), st));
     }
     if (d_ids) HIP_TRY(ctx, hipMemsetAsync(d_ids, 0, g.out_slots * sizeof(int32_t), st));
     dim3 grid(ctx->grid), block(RT_BLOCK);
@@ -1827,10 +1897,10 @@ extern "C" int rt_render_device(rt_ctx *ctx, const rt_render_params *p, float *d
         PROF_MARK(0);
         if (prof) hipLaunchKernelGGL(k_gen, grid, block, 0, st, gp, ctx->q[0], ctx->ctl);
         PROF_MARK(1);
-        if (int rc = enqueue_levels(ctx, p, sh, rec, d_ids, st, ctx->fb0, prof ? nullptr : &gp)) return rc;
+        if (int rc = enqueue_levels(ctx, p, sh, rec, d_ids, st, ctx->fb0, prof ? nullptr : &gp, ctx->fbm)) return rc;
     }
     PROF_MARK(2 + 6 * (rec + 1));
-    if (d_rgb || d_rgb8) hipLaunchKernelGGL(k_resolve, grid, block, 0, st, ctx->fb, ctx->fb0, g.out_slots * 3, d_rgb, d_rgb8);
+    if (d_rgb || d_rgb8) hipLaunchKernelGGL(k_resolve, grid, block, 0, st, ctx->fb, ctx->fb0, ctx->fbm, g.out_slots * 3, d_rgb, d_rgb8);
     PROF_MARK(3 + 6 * (rec + 1));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctl, ctx->ctl, sizeof(FrameCtl), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
@@ -1990,7 +2060,7 @@ extern "C" int rt_render_mean(rt_ctx *ctx, const rt_render_params *p, int32_t fr
         }
         if (rc != RT_OK) break;
         const bool last = k + 1 == frames;
-        hipLaunchKernelGGL(k_accumulate, dim3(ctx->grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->fb, ctx->fb0, ctx->acc,
+        hipLaunchKernelGGL(k_accumulate, dim3(ctx->grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->fb, ctx->fb0, ctx->fbm, ctx->acc,
                            g.out_slots * 3, k == 0 ? 1 : 0, last ? (double)frames : 0.0, d_rgb, d_rgb8);
         sum.primary_rays += st.primary_rays; sum.shadow_rays += st.shadow_rays; sum.reflect_rays += st.reflect_rays;
         sum.transmit_rays += st.transmit_rays; sum.hits += st.hits; sum.ms_total += st.ms_total;
@@ -2045,7 +2115,7 @@ extern "C" int rt_trace(rt_ctx *ctx, const rt_render_params *p, const double *or
             rt_render_params pp = *p;
             pp.flags &= ~RT_FLAG_PROFILE;
             ctx->prof_levels = -1;
-            rc = enqueue_levels(ctx, &pp, sh, rec, nullptr, st, ctx->fb, nullptr);   // one framebuffer: rgb_out is its raw float64 content
+            rc = enqueue_levels(ctx, &pp, sh, rec, nullptr, st, ctx->fb, nullptr, ctx->fb);   // one framebuffer: rgb_out is its raw float64 content
             if (rc != RT_OK) break;
         }
         TRY_T(hipMemcpyAsync(ctx->h_ctl, ctx->ctl, sizeof(FrameCtl), hipMemcpyDeviceToHost, st));

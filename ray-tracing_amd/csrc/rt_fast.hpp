@@ -175,46 +175,57 @@ __device__ __forceinline__ void fast_nearest(const DScene &S, const FastScene &F
         }
         // ---- leaf ----
         {
-            // the next entry's record is requested before the current one is looked at: a leaf costs about
-            // one memory round trip per two entries instead of one per entry (this loop is latency bound)
+            // four entries are requested together and rejected in float32 together: a leaf (<= 10 entries unless it
+            // ended through the EPSILON rule) costs one to three memory round trips instead of one per entry.  The
+            // survivors are confirmed one after the other, in leaf order, by a single copy of the float64 code.
             const uint32_t first = nd.a, last = nd.a + (nd.b >> 2) - 1u;
-            LeafF nxt = F.leaves[first];
-            for (uint32_t e = first; e <= last; ++e) {
-                const LeafF lf = nxt;
-                nxt = F.leaves[e < last ? e + 1u : last];
-                const uint32_t kind = lf.pk & 3u, prim = lf.pk >> 2;
+            for (uint32_t e0 = first; e0 <= last; e0 += 4u) {
+                LeafF lf4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) lf4[k] = F.leaves[min(e0 + (uint32_t)k, last)];
                 const float tcur = st.tbest;
-                bool cand;
-                if (kind == 1u) {
-                    const float px = (lf.x - of0) + (lf.lx - ol0);
-                    const float py = (lf.y - of1) + (lf.ly - ol1);
-                    const float pz = (lf.z - of2) + (lf.lz - ol2);
-                    const float b = fmaf(px, df0, fmaf(py, df1, pz * df2));
-                    const float pp = fmaf(px, px, fmaf(py, py, pz * pz));
-                    const float r2 = lf.r * lf.r;
-                    const float disc = fmaf(b, b, -af * (pp - r2));
-                    const float ed = af * (RT_2M18 * (pp + r2));
-                    cand = !(disc < -ed);
-                    // both roots certainly behind the origin
-                    if ((b < 0.0f) && (b * b > RT_2M38 * pp * af) && (pp - r2 > RT_2M19 * (pp + r2))) cand = false;
-                    // sphere certainly beyond the part of the ray that can matter
-                    const float far = fmaf(tcur, dnf, lf.r);
-                    if (pp > far * far * 1.00001f) cand = false;
-                } else {
-                    float a0 = (lf.x - of0) * in0, b0 = (lf.lx - of0) * in0;
-                    float a1 = (lf.y - of1) * in1, b1 = (lf.ly - of1) * in1;
-                    float a2 = (lf.z - of2) * in2, b2 = (lf.lz - of2) * in2;
-                    float n0 = fminf(a0, b0), x0 = fmaxf(a0, b0);
-                    float n1 = fminf(a1, b1), x1 = fmaxf(a1, b1);
-                    float n2 = fminf(a2, b2), x2 = fmaxf(a2, b2);
-                    n0 -= fmaf(fabsf(n0), RT_2M20, E0); x0 += fmaf(fabsf(x0), RT_2M20, E0);
-                    n1 -= fmaf(fabsf(n1), RT_2M20, E1); x1 += fmaf(fabsf(x1), RT_2M20, E1);
-                    n2 -= fmaf(fabsf(n2), RT_2M20, E2); x2 += fmaf(fabsf(x2), RT_2M20, E2);
-                    const float tn = fmaxf(fmaxf(n0, n1), n2), tf = fminf(fminf(x0, x1), x2);
-                    cand = !(tn > tf) && !(tf < 0.0f) && !(tn > tcur);
+                uint32_t mask = 0u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const LeafF &lf = lf4[k];
+                    const uint32_t kind = lf.pk & 3u;
+                    bool cand;
+                    if (kind == 1u) {
+                        const float px = (lf.x - of0) + (lf.lx - ol0);
+                        const float py = (lf.y - of1) + (lf.ly - ol1);
+                        const float pz = (lf.z - of2) + (lf.lz - ol2);
+                        const float b = fmaf(px, df0, fmaf(py, df1, pz * df2));
+                        const float pp = fmaf(px, px, fmaf(py, py, pz * pz));
+                        const float r2 = lf.r * lf.r;
+                        const float disc = fmaf(b, b, -af * (pp - r2));
+                        const float ed = af * (RT_2M18 * (pp + r2));
+                        cand = !(disc < -ed);
+                        // both roots certainly behind the origin
+                        if ((b < 0.0f) && (b * b > RT_2M38 * pp * af) && (pp - r2 > RT_2M19 * (pp + r2))) cand = false;
+                        // sphere certainly beyond the part of the ray that can matter
+                        const float far = fmaf(tcur, dnf, lf.r);
+                        if (pp > far * far * 1.00001f) cand = false;
+                    } else {
+                        float a0 = (lf.x - of0) * in0, b0 = (lf.lx - of0) * in0;
+                        float a1 = (lf.y - of1) * in1, b1 = (lf.ly - of1) * in1;
+                        float a2 = (lf.z - of2) * in2, b2 = (lf.lz - of2) * in2;
+                        float n0 = fminf(a0, b0), x0 = fmaxf(a0, b0);
+                        float n1 = fminf(a1, b1), x1 = fmaxf(a1, b1);
+                        float n2 = fminf(a2, b2), x2 = fmaxf(a2, b2);
+                        n0 -= fmaf(fabsf(n0), RT_2M20, E0); x0 += fmaf(fabsf(x0), RT_2M20, E0);
+                        n1 -= fmaf(fabsf(n1), RT_2M20, E1); x1 += fmaf(fabsf(x1), RT_2M20, E1);
+                        n2 -= fmaf(fabsf(n2), RT_2M20, E2); x2 += fmaf(fabsf(x2), RT_2M20, E2);
+                        const float tn = fmaxf(fmaxf(n0, n1), n2), tf = fminf(fminf(x0, x1), x2);
+                        cand = !(tn > tf) && !(tf < 0.0f) && !(tn > tcur);
+                    }
+                    if (cand && e0 + (uint32_t)k <= last) mask |= 1u << k;
                 }
-                if (cand) {
-                    const DPrim *pr = S.prims + prim;
+                while (mask) {
+                    const int k = __builtin_ctz(mask);
+                    mask &= mask - 1u;
+                    const uint32_t pk = k == 0 ? lf4[0].pk : (k == 1 ? lf4[1].pk : (k == 2 ? lf4[2].pk : lf4[3].pk));
+                    const uint32_t kind = pk & 3u;
+                    const DPrim *pr = S.prims + (pk >> 2);
                     double t;
                     if (kind == 1u) {
                         if (sphere_exact(o, d, dot3(d, d), pr->a, pr->b[0], t)) fast_consider(S, st, o, d, t, pr->id, early_dist);

@@ -20,17 +20,22 @@ def main():
     ap.add_argument("--rec-max", type=int, default=None)
     ap.add_argument("--no-jitter", action="store_true")
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--world", type=int, default=1, help="render only the tiles of one rank of a tile-partitioned frame")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernel families with events (keeps the overlapped schedule)")
     a = ap.parse_args()
     import bench
     from ray_tracing_amd import abi, native
-    scene = bench.build_scene(a.workload)
+    scene, _ = bench.build_scene(a.workload)
     with native.Context(scene.packed) as ctx:
+        ms = []
         for k in range(a.frames):
-            out = ctx.render(abi.render_params(a.width, a.height, sh_rays=a.sh_rays, rec_max=a.rec_max,
+            out = ctx.render(abi.render_params(a.width, a.height, sh_rays=a.sh_rays, rec_max=a.rec_max, rank=a.rank, world=a.world,
                                                jitter=not a.no_jitter, seed=k, flags=a.flags | (0 if a.no_profile else abi.RT_FLAG_PROFILE)),
                              want_rgb=False, want_ids=False)
+            ms.append(round(out["stats"]["ms_total"], 3))
         st = out["stats"]
+        print("ms_total per frame:", ms)
         print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()})
 
 
