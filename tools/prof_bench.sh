@@ -11,5 +11,5 @@ python - "$tag" <<'PY'
 import csv, glob, sys
 f = glob.glob("gpurun_out/%s/prof/*/*kernel_stats.csv" % sys.argv[1])[0]
 for row in csv.DictReader(open(f)):
-    print("%-60s calls %6s  total %10.3f ms  avg %10.1f us  %5s%%" % (row["Name"].split("(")[0][:60], row["Calls"], float(row["TotalDurationNs"]) / 1e6, float(row["AverageNs"]) / 1e3, row["Percentage"]))
+    print("%-60s calls %6s  total %10.3f ms  avg %10.1f us  %5s%%" % (row["Name"].replace("(anonymous namespace)::", "").split("(")[0][:60], row["Calls"], float(row["TotalDurationNs"]) / 1e6, float(row["AverageNs"]) / 1e3, row["Percentage"]))
 PY
