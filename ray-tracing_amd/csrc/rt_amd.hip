@@ -1791,7 +1791,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         lp.level = 0; lp.last_level = 0;
         hipLaunchKernelGGL(k_shade<RT_SHADE_SPAWN>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s2_, ctx->S, lp, ctx->q[0], ctx->q[1], ctx->hb, ctx->ctl, ctx->fb,
                            ctx->beam.litbits, ctx->beam.pair_slot, ctx->beam.queue_n);
-        static const bool no_pipe = getenv("RT_AMD_NO_PIPELINE") != nullptr;
+        const bool no_pipe = getenv("RT_AMD_NO_PIPELINE") != nullptr;
         if (ctx->three_sets && rec >= 2 && !no_pipe) {
             hipStream_t s3_ = ctx->stream3;
             while ((int)ctx->ev_hit.size() <= rec) {

@@ -347,6 +347,29 @@ def test_overlapped_levels_equal_sequential_levels(gpu_ctx, tag, w, h, sh, rec):
             assert ovl["stats"][key] == seq["stats"][key], key
 
 
+@pytest.mark.parametrize("env", [{"RT_AMD_SETS": "1"}, {"RT_AMD_SETS": "2"}, {"RT_AMD_NO_PIPELINE": "1"}])
+def test_schedules_with_fewer_buffer_sets_give_the_same_frames(gpu_ctx, env):
+    """Three buffer sets: levels 1.. pipelined over two streams; two: levels 1.. on one stream beside level 0; one: all
+    levels in sequence.  The frame does not depend on it (float32 outputs equal, counters equal)."""
+    w, h = 192, 108
+    kw = dict(sh_rays=3, rec_max=6, jitter=True)
+    ref = [gpu_ctx("small").render(abi.render_params(w, h, seed=s, **kw)) for s in (11, 12)]
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        with native.Context(load_scene("small")["packed"]) as ctx:
+            got = [ctx.render(abi.render_params(w, h, seed=s, **kw)) for s in (11, 12)]
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    for a, b in zip(got, ref):
+        assert np.array_equal(a["ids"], b["ids"]) and np.array_equal(a["rgb"], b["rgb"])
+        assert a["stats"]["rays"] == b["stats"]["rays"] and a["stats"]["levels"] == b["stats"]["levels"]
+
+
 def test_mixed_lattice_with_transparency_equals_exact_walk(oracle):
     """BASELINE.json configs[4] in small: spheres and boxes alternating on a lattice, 25 % reflective, 15 % transparent,
     recursion 10 (tools/gen_scene.synth_mixed, grid 40 = 1600 primitives).  Default path == exact walk bit for bit,
