@@ -95,10 +95,16 @@ __global__ void __launch_bounds__(BT) k_bounds_partial(const double *small, cons
 
 __global__ void k_bounds_final(const double *partial, int nparts, const double *given_lo, const double *given_hi,
                                double *lo, double *hi) {
-    const int k = threadIdx.x;
+    // one wave per component: lanes stride over the partial results, then a butterfly
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (k >= 6) return;
-    double v = partial[k];
-    for (int b = 1; b < nparts; ++b) v = k < 3 ? fmin(v, partial[6 * b + k]) : fmax(v, partial[6 * b + k]);
+    double v = k < 3 ? INFINITY : -INFINITY;
+    for (int b = lane; b < nparts; b += 64) v = k < 3 ? fmin(v, partial[6 * b + k]) : fmax(v, partial[6 * b + k]);
+    for (int d = 32; d; d >>= 1) {
+        const double o = __shfl_xor(v, d);
+        v = k < 3 ? fmin(v, o) : fmax(v, o);
+    }
+    if (lane) return;
     if (k < 3) lo[k] = given_lo ? given_lo[k] : v;
     else hi[k - 3] = given_hi ? given_hi[k - 3] : v;
 }
@@ -390,7 +396,7 @@ int build(rt_bsp *t, int64_t n, const double *small, const double *big, const do
     if (int rc = alloc_level(t, lv[0], 1, (uint32_t)n)) return rc;
     HIP_B(hipEventRecord(ev0, t->stream));
     hipLaunchKernelGGL(k_bounds_partial, dim3(nparts), dim3(BT), 0, t->stream, d_small, d_big, n, d_partial);
-    hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(64), 0, t->stream, d_partial, nparts, root_lo ? d_given : nullptr,
+    hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(6 * 64), 0, t->stream, d_partial, nparts, root_lo ? d_given : nullptr,
                        root_hi ? d_given + 3 : nullptr, lv[0].lo, lv[0].hi);
     hipLaunchKernelGGL(k_init_refs, dim3(blocks_for(n)), dim3(BT), 0, t->stream, lv[0]);
     t->st.launches += 3;

@@ -370,6 +370,36 @@ def test_schedules_with_fewer_buffer_sets_give_the_same_frames(gpu_ctx, env):
         assert a["stats"]["rays"] == b["stats"]["rays"] and a["stats"]["levels"] == b["stats"]["levels"]
 
 
+def test_queue_overflow_grows_the_queues_and_renders_again(oracle, tmp_path):
+    """Every hit in this scene spawns a through-ray AND a mirror ray, so level L holds up to 2^L rays per pixel:
+    the queues (2 x the primary slots to begin with) overflow, rt_sync_stats reports it, the growth factor doubles and
+    rt_render renders again until the frame fits.  The frame that comes out equals the oracle's."""
+    from ray_tracing_amd import scene_pack
+    from Parser import parse_scene_file
+    from BSPNode import BSPNode
+    text = ["cam 0 1 -6  0 0.8 0  0 1 0  1.2 1", "set 0.2 0.3 0.5 2 3",
+            "mtl 0.6 0.6 0.6  0.5 0.5 0.5  0.5 0.5 0.5  20 0.5",
+            "pln 0 1 0 -1 1", "pln 0 0 -1 -6 1", "pln 1 0 0 -5 1", "pln -1 0 0 -5 1"]
+    for k in range(12):
+        text.append("sph %g %g %g 0.9 1" % (-3.3 + 2.2 * (k % 4), 0.2 + 1.9 * (k // 4), 1.0 + 0.4 * (k % 3)))
+    text.append("lgt 0 6 -4  1 1 1  1 0.8 1")
+    p = tmp_path / "glass.txt"
+    p.write_text("\n".join(text) + "\n")
+    cam, st, _o, surfaces, mats, lights = parse_scene_file(str(p))
+    packed = scene_pack.pack_scene(surfaces, mats, lights, cam, st, BSPNode.build_bsp_tree(surfaces))
+    prm = abi.render_params(96, 54, jitter=True, seed=3)
+    ref = oracle.render(packed, prm)
+    with native.Context(packed) as ctx:
+        first = ctx.render(prm)
+        again = ctx.render(prm)                  # queues are large enough now: one pass
+    assert first["stats"]["max_queue"] > 2 * 96 * 54          # more rays on one level than the initial queues held
+    for out in (first, again):
+        assert np.array_equal(out["ids"], ref["ids"])
+        assert np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
+        for key in ("primary_rays", "shadow_rays", "reflect_rays", "transmit_rays", "hits"):
+            assert out["stats"][key] == ref["counters"][key], key
+
+
 def test_mixed_lattice_with_transparency_equals_exact_walk(oracle):
     """BASELINE.json configs[4] in small: spheres and boxes alternating on a lattice, 25 % reflective, 15 % transparent,
     recursion 10 (tools/gen_scene.synth_mixed, grid 40 = 1600 primitives).  Default path == exact walk bit for bit,

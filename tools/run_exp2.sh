@@ -1,8 +1,7 @@
 set -e
 cd /root/repo
-for env in "RT_AMD_X=1" "RT_AMD_NO_PRIO=1" "RT_AMD_OVL_MAIN=4 RT_AMD_OVL_MAIN2=4" "RT_AMD_NO_PRIO=1 RT_AMD_OVL_MAIN=4 RT_AMD_OVL_MAIN2=4" "RT_AMD_OVL_SIDE=2" "RT_AMD_NO_PIPELINE=1"; do
-  for args in "--width 3840 --height 2160 --world 8 --rank 0" "--width 1920 --height 1080" "--width 3840 --height 2160"; do
-    echo "== $env $args"
-    env $env timeout -k 10 200 python tools/prof_frame.py --frames 12 --no-profile $args 2>&1 | grep ms_total
-  done
-done
+rm -rf gpurun_out/pmc_gen
+bash tools/pmc.sh pmc_gen --frames 1 --no-profile > gpurun_out/pmc_gen.log 2>&1 || { tail gpurun_out/pmc_gen.log; exit 1; }
+bash tools/pmc2.sh pmc_gen2 --frames 1 --no-profile >> gpurun_out/pmc_gen.log 2>&1 || true
+python tools/pmc_summary.py gpurun_out/pmc_gen "k_intersect<true, true>"
+python tools/pmc_summary.py gpurun_out/pmc_gen2 "k_intersect<true, true>"
