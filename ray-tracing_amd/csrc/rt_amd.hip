@@ -17,6 +17,8 @@
 // The colour recursion  colour = through*T + (diff+spec)*(1-T) + refl*Kr  is linear in the child
 // colours, so each queued ray carries a throughput and adds throughput*local to its pixel.
 #include <hip/hip_runtime.h>
+
+#include <chrono>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1252,7 +1254,16 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
     if (!out) return fail(nullptr, RT_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     std::string why;
+    const bool trace_create = getenv("RT_AMD_DEBUG") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto tick = [&](const char *what) {       // RT_AMD_DEBUG: where the set-up time of a large scene goes
+        if (!trace_create) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[rt_amd] rt_create %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     if (int rc = check_scene(s, why)) return fail(nullptr, rc, why);
+    tick("check_scene");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device visible");
     if (device < 0 || device >= ndev) return fail(nullptr, RT_ERR_NO_DEVICE, "device ordinal out of range");
@@ -1282,6 +1293,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
     ctx->grid = prop.multiProcessorCount * 8;
     ctx->grid = (ctx->grid + 7) & ~7;
 
+    tick("context, stream, events");
     // ---- primitives: spheres first, then boxes ----
     const int ns = s->n_spheres, nb = s->n_boxes;
     std::vector<DPrim> prims((size_t)ns + nb);
@@ -1311,6 +1323,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
     TRY_C(upload(ctx, ctx->scene_allocs, prims, &ctx->S.prims));
     TRY_C(upload(ctx, ctx->scene_allocs, fprims, &ctx->S.fprims));
 
+    tick("primitive tables + upload");
     // ---- nodes, with skip links ----
     const int nn = s->n_nodes;
     std::vector<DNode> nodes(nn);
@@ -1339,6 +1352,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
     std::vector<int32_t> leaf(s->leaf_prim, s->leaf_prim + s->n_leaf_refs);
     TRY_C(upload(ctx, ctx->scene_allocs, leaf, &ctx->S.leaf_prim));
 
+    tick("node tables + upload");
     // ---- kd view of the same tree for the fast path (rt_fast.hpp) ----
     {
         std::vector<KNode> kn(nn);
@@ -1423,6 +1437,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
         if (getenv("RT_AMD_DEBUG")) fprintf(stderr, "[rt_amd] kd view: ok=%d depth=%d lds=%zu B\n", ctx->F.ok, max_depth, ctx->lds_bytes);
     }
 
+    tick("kd view + upload");
     // ---- grid = exactly the workgroups that are resident at once (every kernel walks its queue with a fixed
     // grid; a second, partially filled round of workgroups would run at a fraction of the occupancy) ----
     {
@@ -1452,6 +1467,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
                     ctx->g_beam_setup, ctx->g_beam, ctx->g_queue, ctx->g_shade);
     }
 
+    tick("occupancy queries");
     // ---- planes / surfaces / materials / lights ----
     std::vector<DPlane> planes(s->n_planes);
     for (int i = 0; i < s->n_planes; ++i) {
@@ -1495,6 +1511,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
     ctx->S.n_mats = s->n_materials; ctx->S.n_lights = s->n_lights; ctx->S.n_shadow_lights = (int)sl.size();
     ctx->S.far_clip = s->far_clip;
     for (int k = 0; k < 3; ++k) ctx->S.bg[k] = s->background[k];
+    tick("surface / material / light tables");
     ctx->host = *s;   // pointers inside are NOT used after this call; scalars (camera, settings) are
 #undef TRY_C
 #undef HIP_C

@@ -1,7 +1,3 @@
-set -e
 cd /root/repo
-rm -rf gpurun_out/pmc_gen
-bash tools/pmc.sh pmc_gen --frames 1 --no-profile > gpurun_out/pmc_gen.log 2>&1 || { tail gpurun_out/pmc_gen.log; exit 1; }
-bash tools/pmc2.sh pmc_gen2 --frames 1 --no-profile >> gpurun_out/pmc_gen.log 2>&1 || true
-python tools/pmc_summary.py gpurun_out/pmc_gen "k_intersect<true, true>"
-python tools/pmc_summary.py gpurun_out/pmc_gen2 "k_intersect<true, true>"
+bash tools/kt.sh s1m --workload synth1M
+RT_AMD_DEBUG=1 timeout -k 10 200 python tools/prof_frame.py --frames 1 --workload synth1M --flags 4096 2>&1 | grep "level\|beam traversal\|listed pairs"
