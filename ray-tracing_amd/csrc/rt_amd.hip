@@ -48,6 +48,7 @@ struct FrameCtl {
     unsigned long long reflect_rays, transmit_rays, primary_rays;
     uint32_t n_listed[RT_MAX_LEVELS + 2];   // diagnostics: pairs that needed the per-ray filter / rays that needed
     uint32_t n_queued[RT_MAX_LEVELS + 2];   // the float64 queue, per level (copied by k_shade)
+    uint32_t n_walked[RT_MAX_LEVELS + 2];   // rays of overflowing pairs (k_shadow_walk)
     uint32_t dbg_max_trips, dbg_pad;        // RT_FLAG 0x1000: longest / total beam traversal of the frame
     uint32_t dbg_why[4];                    // pairs sent to the queue: delicate basis, touched list, units, dedup list
     unsigned long long dbg_sum_trips;
@@ -88,6 +89,8 @@ struct LevelParams {
     uint32_t spb, magic_s2, magic_s;     // magic_x = ceil(2^32 / x): n / x == __umulhi(n, magic_x) for n < 2^16
     int32_t beam;                        // this frame's soft shadows go through the beam path
     int32_t prio;                        // overlapped frame, deeper levels: raise the waves' issue priority
+    uint32_t walk_min;                   // rays of overflowing pairs: k_shadow_walk takes them when a level has at least this
+                                         // many, else k_shadow_queue expands them (same verdicts either way)
 };
 
 // XCD-aware chunk walk.  A chunk is RT_BLOCK consecutive items; chunks are dealt to the 8 XCDs in groups of
@@ -373,8 +376,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_setup(DScene S, LevelParams
 // Wave-private append: values are parked in the wave's LDS buffer (128 entries) and get their slots 64 at a time -
 // ONE returning atomic on the counter per 64 values (returning atomics on a single address complete at ~30 ns
 // each; one per wave and chunk was the bottleneck of the kernels that append).  All 64 lanes call these together.
-template <typename Store>
-__device__ __forceinline__ void wave_append(bool flag, uint32_t value, uint32_t *buf, uint32_t &n, uint32_t *counter, int lane, Store store) {
+template <typename T, typename Store>
+__device__ __forceinline__ void wave_append(bool flag, T value, T *buf, uint32_t &n, uint32_t *counter, int lane, Store store) {
     const unsigned long long m = __ballot(flag);
     if (!m) return;
     if (flag) buf[n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
@@ -386,7 +389,7 @@ __device__ __forceinline__ void wave_append(bool flag, uint32_t value, uint32_t 
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(counter, 64u);
         base = __shfl(base, 0);
-        const uint32_t v = buf[lane], v2 = buf[64 + lane];
+        const T v = buf[lane], v2 = buf[64 + lane];
         store(base + (uint32_t)lane, v);
         n -= 64u;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -396,8 +399,8 @@ __device__ __forceinline__ void wave_append(bool flag, uint32_t value, uint32_t 
         __builtin_amdgcn_wave_barrier();
     }
 }
-template <typename Store>
-__device__ __forceinline__ void wave_append_flush(uint32_t *buf, uint32_t n, uint32_t *counter, int lane, Store store) {
+template <typename T, typename Store>
+__device__ __forceinline__ void wave_append_flush(T *buf, uint32_t n, uint32_t *counter, int lane, Store store) {
     if (!n) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -530,9 +533,16 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                 else if (bo.nu == 0 && n_eval == 0) whole = (n_atp + (bo.atp_all ? 1u : 0u)) > 0 ? RT_PAIR_LIT : RT_PAIR_UNLIT;
             }
             if (whole) bb.pair_slot[(uint64_t)ml * lp.cap + h] = whole;
-            else if (bo.overflow) {                         // all its rays go to the float64 kernel, which expands the pair itself
+            else if (bo.overflow) {
+                // too many primitives along the beam (or a delicate basis): k_shadow_walk sends each ray through the
+                // tree on its own; it needs the header only.  units = RT_META_OVERFLOW: float64 for every ray.
                 ovf = true;
-                bb.pair_slot[(uint64_t)ml * lp.cap + h] = RT_PAIR_UNLIT;   // nothing from the filter: the lit count is the queue kernel's alone
+                bb.pair_slot[(uint64_t)ml * lp.cap + h] = RT_PAIR_UNLIT;   // nothing from the per-pair filter: the lit count is hb.lit alone
+                const uint32_t meta = (delicate ? RT_META_OVERFLOW : 0u) | ((uint32_t)m << 16) | (pcls << 24);
+                rec[0] = make_float4(q00, q01, q02, g);
+                rec[1] = make_float4(u0, u1, u2, __uint_as_float(meta));
+                rec[2] = make_float4(r0, r1, r2, __uint_as_float(q.gpix[r]));
+                rec[3] = make_float4(pd[0], pd[1], pd[2], __uint_as_float(q.path[r]));
             } else {
                 listed = true;                              // only now the header is worth its 64 bytes (13 % of the pairs)
                 const uint32_t meta = bo.nu | (bo.boxmask << 4) | ((uint32_t)m << 16) | (pcls << 24) | (bo.atp_all ? 1u << 30 : 0u);
@@ -839,6 +849,98 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
     }
 }
 
+// one lane per soft-shadow ray of the pairs in ovlist (their beam met more primitives than a pair record holds):
+// the ray is derived from the pair header exactly as in k_shadow_beam and walks the tree itself (ray_walk,
+// rt_shadow.hpp) - float32 filtered predicates on float64-derived operands, undecided rays to the float64 queue.
+// Lanes of one pair are neighbours: s*s consecutive items.
+__global__ void __launch_bounds__(RT_BLOCK) k_shadow_walk(DScene S, FastScene F, LevelParams lp, HitBuf hb, BeamBuf bb, FrameCtl *ctl) {
+    extern __shared__ uint2 lds_stack[];
+    __shared__ unsigned long long qbuf_all[(RT_BLOCK / 64) * 128];
+    uint2 *stk = lds_stack + threadIdx.x;
+    const uint32_t s = (uint32_t)lp.sh_rays, s2 = s * s;
+    const uint64_t total = (uint64_t)bb.queue_n[2] * s2;
+    if (ctl->overflow || total < (uint64_t)lp.walk_min || total == 0) return;     // few such rays: k_shadow_queue takes them
+    if (lp.prio) __builtin_amdgcn_s_setprio(3);
+    const uint32_t queue_cap = bb.queue_n[3];
+    const int lane = threadIdx.x & 63;
+    unsigned long long *qbuf = qbuf_all + (threadIdx.x >> 6) * 128;
+    uint32_t qn = 0u;
+    auto store_q = [&](uint32_t slot, unsigned long long v) {
+        if (slot < queue_cap) bb.queue[slot] = v;
+        else ctl->overflow = 1;                       // frame is void; the host re-renders with a larger queue
+    };
+    float pn[RT_PMAX][3];
+    for (int k = 0; k < RT_PMAX; ++k)
+        for (int c = 0; c < 3; ++c) pn[k][c] = k < S.n_planes ? (float)S.planes[k].n[c] : 0.0f;
+    ChunkWalk walk(total);
+    uint64_t first;
+    while (walk.next(first)) {
+        const uint64_t i = first + threadIdx.x;
+        const bool active = i < total;
+        bool lit = false, unsure = false;
+        uint32_t seg = 0u, kk = 0u;
+        if (active) {
+            const uint32_t pi = (uint32_t)(i / s2);
+            kk = (uint32_t)(i - (uint64_t)pi * s2);
+            seg = bb.ovlist[pi];
+            const float4 *rec = bb.rec + (uint64_t)seg * RT_PAIR_UNITS;
+            const float4 h0 = rec[0], h1 = rec[1], h2 = rec[2], h3 = rec[3];
+            const float g = h0.w;
+            const uint32_t meta = __float_as_uint(h1.w);
+            if ((meta & 0xfu) == RT_META_OVERFLOW) unsure = true;
+            else {
+                const uint32_t a = kk / s, b = kk - a * s;            // Light.py:265: jj = a, ii = b
+                float j10 = 0, j11 = 0, j12 = 0, j20 = 0, j21 = 0, j22 = 0;
+                if (lp.jitter) {                     // jitter6() of the oracle, in float32 (as in k_shadow_beam)
+                    const uint32_t m = (meta >> 16) & 0xffu;
+                    const float k16 = 1.0f / 65536.0f, g2 = 2.0f * g;
+                    uint32_t x = __float_as_uint(h2.w), y = __float_as_uint(h3.w) * 0x9E3779B1u + m, z = lp.seed * 0x85EBCA6Bu + kk;
+                    pcg3d(x, y, z);
+                    j10 = fmaf(g2, (float)(x >> 16) * k16, -g); j11 = fmaf(g2, (float)(y >> 16) * k16, -g);
+                    j12 = fmaf(g2, (float)(z >> 16) * k16, -g);
+                    j20 = fmaf(g2, (float)(x & 0xffffu) * k16, -g); j21 = fmaf(g2, (float)(y & 0xffffu) * k16, -g);
+                    j22 = fmaf(g2, (float)(z & 0xffffu) * k16, -g);
+                }
+                const float bg = (float)b * g, ag = (float)a * g;
+                const float sw0 = h0.x - bg * h1.x + ag * h2.x + (j10 * h1.x + j20 * h2.x);
+                const float sw1 = h0.y - bg * h1.y + ag * h2.y + (j11 * h1.y + j21 * h2.y);
+                const float sw2 = h0.z - bg * h1.z + ag * h2.z + (j12 * h1.z + j22 * h2.z);
+                const float ww = fmaf(sw0, sw0, fmaf(sw1, sw1, sw2 * sw2));
+                const float inv_nv = __builtin_amdgcn_rsqf(ww);
+                const float nv = ww * inv_nv;
+                const float nvlim = nv - fmaf(nv, 4.0f * RT_RHO, 1e-5f);
+                const float w0 = sw0 * inv_nv, w1 = sw1 * inv_nv, w2 = sw2 * inv_nv;
+                int verdict = (!(nv > 1e-4f) || !(nv < 1e7f)) ? SH_UNSURE : 0;
+                int n_atp = 0;
+                const float pdk[RT_PMAX] = {h3.x, h3.y, h3.z};
+                const uint32_t pcls = (meta >> 24) & 0x3fu;
+#pragma unroll
+                for (int k = 0; k < RT_PMAX; ++k) {
+                    if (k < S.n_planes) {
+                        const uint32_t cls = (pcls >> (2 * k)) & 3u;
+                        if (cls == RT_PLANE_EVAL) {
+                            const int v = sh_plane(pn[k][0], pn[k][1], pn[k][2], pdk[k], w0, w1, w2, nv, nvlim);
+                            verdict |= v;
+                            n_atp += v & SH_ATP;
+                        } else n_atp += cls == RT_PLANE_ATP;
+                    }
+                }
+                if (!(verdict & (SH_OCCLUDE | SH_UNSURE))) {     // (an unsure ray is decided in float64 whatever the walk finds)
+                    const uint32_t r = hb.list[seg / (uint32_t)S.n_shadow_lights];
+                    const d3 P = mk3(hb.px[r], hb.py[r], hb.pz[r]);
+                    verdict |= ray_walk<RT_BLOCK>(S, F, stk, P, sw0, sw1, sw2, w0, w1, w2, nv, nvlim, n_atp);
+                }
+                if (verdict & SH_OCCLUDE) unsure = false;
+                else if (verdict & SH_UNSURE) unsure = true;
+                else lit = n_atp > 0;
+            }
+        }
+        if (lit) atomicAdd(&hb.lit[seg], 1u);
+        wave_append(unsure, (unsigned long long)seg * s2 + kk, qbuf, qn, &bb.queue_n[0], lane, store_q);
+    }
+    wave_append_flush(qbuf, qn, &bb.queue_n[0], lane, store_q);
+}
+
 // the rays the filter could not decide, in float64
 __global__ void __launch_bounds__(RT_BLOCK) k_shadow_queue(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb, SegBuf sg,
                                                            BeamBuf bb, FrameCtl *ctl) {
@@ -850,7 +952,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_queue(DScene S, FastScene F
     // overflow, delicate basis): those are expanded here, s*s consecutive items per pair
     const uint32_t n = min(bb.queue_n[0], bb.queue_n[3]);
     const uint32_t s2 = (uint32_t)(lp.sh_rays * lp.sh_rays);
-    const uint64_t total = (uint64_t)n + (uint64_t)bb.queue_n[2] * s2;
+    const uint64_t n_ovf = (uint64_t)bb.queue_n[2] * s2;
+    const uint64_t total = (uint64_t)n + (n_ovf < (uint64_t)lp.walk_min ? n_ovf : 0ull);   // else k_shadow_walk has dealt with them
     ChunkWalk walk(total);
     uint64_t first;
     while (walk.next(first)) {
@@ -877,7 +980,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, LevelParams lp, Ra
                                                     double *fb, const unsigned long long *litbits, const uint32_t *pair_slot, const uint32_t *queue_n) {
     if (ctl->overflow) return;
     if (lp.prio) __builtin_amdgcn_s_setprio(3);
-    if ((MODE & RT_SHADE_LIGHTS) && lp.beam && blockIdx.x == 0 && threadIdx.x == 0) { ctl->n_queued[lp.level] = queue_n[0] + queue_n[2] * (uint32_t)(lp.sh_rays * lp.sh_rays); ctl->n_listed[lp.level] = queue_n[1]; }
+    if ((MODE & RT_SHADE_LIGHTS) && lp.beam && blockIdx.x == 0 && threadIdx.x == 0) { ctl->n_queued[lp.level] = queue_n[0]; ctl->n_listed[lp.level] = queue_n[1]; ctl->n_walked[lp.level] = queue_n[2] * (uint32_t)(lp.sh_rays * lp.sh_rays); }
     const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
     const uint32_t nsl = (uint32_t)S.n_shadow_lights;
     const double s2 = (double)(lp.sh_rays * lp.sh_rays);
@@ -1160,7 +1263,8 @@ struct rt_ctx {
     bool two_sets = false;                  // hb1 / seg1 / beam1 are separate allocations
     hipStream_t stream2 = nullptr;          // the deeper levels of an overlapped frame
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int nb_intersect = 1, nb_beam_setup = 1, nb_beam = 1, nb_queue = 1, nb_shade = 1, nb_setup = 1, nb_shadow = 1;   // workgroups per CU
+    int nb_intersect = 1, nb_beam_setup = 1, nb_beam = 1, nb_queue = 1, nb_shade = 1, nb_setup = 1, nb_shadow = 1, nb_walk = 1;   // workgroups per CU
+    int g_walk = 2048;
     FrameCtl *ctl = nullptr;
     FrameCtl *h_ctl = nullptr;   // pinned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1431,6 +1535,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
             HIP_C(hipFuncSetAttribute((const void *)&k_intersect<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow_queue, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+            HIP_C(hipFuncSetAttribute((const void *)&k_shadow_walk, hipFuncAttributeMaxDynamicSharedMemorySize, big - 8192));   // 4 KB of static LDS (queue buffer)
             HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));   // 14 KB of static LDS (list buffer, touched entries)
             HIP_C(hipFuncSetAttribute((const void *)&k_intersect_only<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         }
@@ -1460,6 +1565,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
         ctx->g_beam_setup = grid_for((const void *)&k_beam_setup, lds); ctx->nb_beam_setup = last_nb;
         ctx->g_beam = grid_for((const void *)&k_shadow_beam, 0); ctx->nb_beam = last_nb;
         ctx->g_queue = grid_for((const void *)&k_shadow_queue, lds); ctx->nb_queue = last_nb;
+        ctx->g_walk = grid_for((const void *)&k_shadow_walk, lds); ctx->nb_walk = last_nb;
         ctx->g_shade = grid_for((const void *)&k_shade<3>, 0); ctx->nb_shade = last_nb;
         ctx->g_setup = grid_for((const void *)&k_shadow_setup, 0); ctx->nb_setup = last_nb;
         if (getenv("RT_AMD_DEBUG"))
@@ -1716,6 +1822,13 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                           double *fb0, const GenParams *gen, double *fbm) {
     LevelParams lp{};
     lp.sh_rays = sh; lp.jitter = p->jitter; lp.seed = p->seed; lp.cap = (uint32_t)ctx->cap; lp.flags = p->flags;
+    {
+        // k_shadow_walk pays when a level has millions of rays in overflowing pairs (1 M lattice: 17 M); with few of them
+        // a second latency-bound kernel only adds its tail.  RT_AMD_WALK_MIN: 1 = always, -1 = never (diagnostic).
+        const char *e = getenv("RT_AMD_WALK_MIN");
+        const long long v = e ? atoll(e) : (3ll << 20);
+        lp.walk_min = v < 0 || v > 0xfffffffell ? 0xffffffffu : (uint32_t)v;
+    }
     dim3 block(RT_BLOCK);
     const bool prof = (p->flags & RT_FLAG_PROFILE) != 0;
     const bool fast = ctx->F.ok && !(p->flags & RT_FLAG_EXACT_TRAVERSAL);
@@ -1748,6 +1861,8 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         if (beam) {
             hipLaunchKernelGGL(k_beam_setup, dim3(gsz(ctx->g_beam_setup, ctx->nb_beam_setup, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
             hipLaunchKernelGGL(k_shadow_beam, dim3(gsz(ctx->g_beam, ctx->nb_beam, side == 1 ? 3 : side)), block, 0, s_, ctx->S, lp, hb, bb, ctx->ctl);
+            if (lp.walk_min != 0xffffffffu)
+                hipLaunchKernelGGL(k_shadow_walk, dim3(gsz(ctx->g_walk, ctx->nb_walk, side == 1 ? 3 : side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, hb, bb, ctx->ctl);
             hipLaunchKernelGGL(k_shadow_queue, dim3(gsz(ctx->g_queue, ctx->nb_queue, side == 1 ? 3 : side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, sg, bb, ctx->ctl);
         } else {
             hipLaunchKernelGGL(k_shadow_setup, dim3(gsz(ctx->g_setup, ctx->nb_setup, side)), block, 0, s_, ctx->S, lp, hb, sg, ctx->ctl);
@@ -1968,8 +2083,8 @@ extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
     if (getenv("RT_AMD_DEBUG") && ctx->beam.rec && c.n_hits[0] > 0) {
         // beam path diagnostics: per level, pairs / pairs that needed the per-ray filter / rays that needed float64
         for (int l = 0; l <= ctx->last_rec && l < RT_MAX_LEVELS; ++l)
-            fprintf(stderr, "[rt_amd] level %d: %llu pairs, %u listed, %u rays queued\n", l,
-                    (unsigned long long)c.n_hits[l] * (unsigned long long)ctx->S.n_shadow_lights, c.n_listed[l], c.n_queued[l]);
+            fprintf(stderr, "[rt_amd] level %d: %llu pairs, %u listed, %u rays of overflowing pairs, %u rays queued by the filters\n", l,
+                    (unsigned long long)c.n_hits[l] * (unsigned long long)ctx->S.n_shadow_lights, c.n_listed[l], c.n_walked[l], c.n_queued[l]);
         fprintf(stderr, "[rt_amd] beam traversal trips (flag 0x1000): max %u, total %llu; pairs to the queue: delicate %u, touched %u, units %u, dedup %u\n",
                 c.dbg_max_trips, c.dbg_sum_trips, c.dbg_why[0], c.dbg_why[1], c.dbg_why[2], c.dbg_why[3]);
         // candidate units of the listed pairs of the LAST level (render with rec_max = 0 to see level 0)

@@ -442,3 +442,120 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
     R.nu = nu; R.boxmask = boxmask;
     return R;
 }
+
+// ---------------------------------------------------------------------------------------------
+// One shadow ray of a pair whose beam met too many primitives (k_beam_setup's candidate overflow): the ray walks
+// the tree itself, as a beam that is only as wide as the float32 uncertainty of its sample, and classifies every
+// primitive it may touch on the spot with the same predicates and the same float64-derived operands as the listed
+// pairs' rays.  Primitives the thin beam provably cannot touch are misses for the exact ray as well; one that
+// appears in several leaves is classified several times, which changes nothing (verdict bits are ORed, only
+// n_atp > 0 matters).  Near child first (smaller lambda): an occluder close to P ends the walk early.
+//   sw  = sample - P (float32, error <= nv RT_RHO per component),  w = sw / nv,  qi = sh_ray_inv(w)
+// Returns the ORed verdict; n_atp counts AT_P verdicts.
+template <int STRIDE>
+__device__ __forceinline__ int ray_walk(const DScene &S, const FastScene &F, uint2 *stk, d3 P, float sw0, float sw1, float sw2, float w0,
+                                        float w1, float w2, float nv, float nvlim, int &n_atp) {
+    int verdict = 0;
+    const float Pf0 = (float)P.x, Pf1 = (float)P.y, Pf2 = (float)P.z;
+    const float Kp = fmaxf(fmaxf(fabsf(Pf0), fabsf(Pf1)), fmaxf(fabsf(Pf2), F.extent));
+    const float E = Kp * RT_2M19 + 2e-6f;
+    const float hs = fmaf(nv, 2.0f * RT_RHO, 1e-6f);                 // the exact sample lies in sw +- hs
+    const float L0 = sw0 - hs, L1 = sw1 - hs, L2 = sw2 - hs, U0 = sw0 + hs, U1 = sw1 + hs, U2 = sw2 + hs;
+    const float iL0 = __builtin_amdgcn_rcpf(L0), iL1 = __builtin_amdgcn_rcpf(L1), iL2 = __builtin_amdgcn_rcpf(L2);
+    const float iU0 = __builtin_amdgcn_rcpf(U0), iU1 = __builtin_amdgcn_rcpf(U1), iU2 = __builtin_amdgcn_rcpf(U2);
+    // cone around w with tan(half angle) kt: sin <= sqrt(3) hs / nv
+    const float kt = 1.7321f * hs * __builtin_amdgcn_rcpf(nv) * 1.01f;
+    float l0 = 0.0f, l1 = 1.0f;
+    clip_mul(l0, l1, -U0, -iU0, -((F.root_lo[0] - Pf0) - E)); clip_mul(l0, l1, L0, iL0, (F.root_hi[0] - Pf0) + E);
+    clip_mul(l0, l1, -U1, -iU1, -((F.root_lo[1] - Pf1) - E)); clip_mul(l0, l1, L1, iL1, (F.root_hi[1] - Pf1) + E);
+    clip_mul(l0, l1, -U2, -iU2, -((F.root_lo[2] - Pf2) - E)); clip_mul(l0, l1, L2, iL2, (F.root_hi[2] - Pf2) + E);
+    if (!(l0 <= l1)) return verdict;
+    const RayInv qi = sh_ray_inv(w0, w1, w2);
+    const uint32_t NONE = 0xffffffffu;
+    uint32_t node = 0;
+    int sp = 0;
+    for (;;) {
+        KNode nd = F.knodes[node];
+        while ((nd.b & 3u) != 3u) {
+            const uint32_t ax = nd.b & 3u;
+            const float cut = __uint_as_float(nd.a) - sel3(ax, Pf0, Pf1, Pf2);
+            const float La = sel3(ax, L0, L1, L2), Ua = sel3(ax, U0, U1, U2), iLa = sel3(ax, iL0, iL1, iL2), iUa = sel3(ax, iU0, iU1, iU2);
+            float a0 = l0, a1 = l1, b0 = l0, b1 = l1;
+            clip_mul(a0, a1, La, iLa, cut + E);          // left child: some beam point with x <= cut
+            clip_mul(b0, b1, -Ua, -iUa, -(cut - E));     // right child: some beam point with x >= cut
+            const bool goL = a0 <= a1, goR = b0 <= b1;
+            const uint32_t left = node + 1u, right = nd.b >> 2;
+            if (goL && goR) {
+                const bool left_first = a0 <= b0;        // the side that holds the part nearer to P
+                stk[sp * STRIDE] = left_first ? make_uint2(right, pack_lambda(b0, b1)) : make_uint2(left, pack_lambda(a0, a1));
+                ++sp;
+                node = left_first ? left : right;
+                l0 = left_first ? a0 : b0;
+                l1 = left_first ? a1 : b1;
+            } else if (goL) { node = left; l0 = a0; l1 = a1; }
+            else if (goR) { node = right; l0 = b0; l1 = b1; }
+            else { node = NONE; break; }
+            nd = F.knodes[node];
+        }
+        if (node != NONE) {
+            const float m0 = fmaxf(l0 - 1e-6f, 0.0f), m1 = fminf(l1 + 1e-6f, 1.0f);
+            const float blo0 = fminf(m0 * L0, m1 * L0) - E, bhi0 = fmaxf(m0 * U0, m1 * U0) + E;
+            const float blo1 = fminf(m0 * L1, m1 * L1) - E, bhi1 = fmaxf(m0 * U1, m1 * U1) + E;
+            const float blo2 = fminf(m0 * L2, m1 * L2) - E, bhi2 = fmaxf(m0 * U2, m1 * U2) + E;
+            // four entries are requested and tested against the thin beam together (one memory round trip instead of
+            // four); the ones it may touch are then classified one after the other
+            const uint32_t e_last = nd.a + (nd.b >> 2) - 1u;
+            for (uint32_t e0 = nd.a; e0 <= e_last; e0 += 4u) {
+                LeafF lf4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) lf4[k] = F.leaves[min(e0 + (uint32_t)k, e_last)];
+                uint32_t mask = 0u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const LeafF &lf = lf4[k];
+                    const bool sph = (lf.pk & 3u) == 1u;
+                    const float rr = sph ? lf.r : 0.0f;
+                    const float c0 = lf.x - Pf0, c1 = lf.y - Pf1, c2 = lf.z - Pf2;
+                    const float d0 = sph ? c0 : lf.lx - Pf0, d1 = sph ? c1 : lf.ly - Pf1, d2 = sph ? c2 : lf.lz - Pf2;
+                    bool touch = !(c0 - rr > bhi0) && !(d0 + rr < blo0) && !(c1 - rr > bhi1) && !(d1 + rr < blo1) &&
+                                 !(c2 - rr > bhi2) && !(d2 + rr < blo2);
+                    // bounding sphere against the thin cone (same test as the beam's, beam_collect)
+                    const float m0_ = sph ? c0 : 0.5f * (c0 + d0), m1_ = sph ? c1 : 0.5f * (c1 + d1), m2_ = sph ? c2 : 0.5f * (c2 + d2);
+                    const float e0_ = d0 - c0, e1_ = d1 - c1, e2_ = d2 - c2;
+                    const float rb = sph ? lf.r : 0.5f * __builtin_amdgcn_sqrtf(fmaf(e0_, e0_, fmaf(e1_, e1_, e2_ * e2_))) * 1.000001f;
+                    const float ta = fmaf(m0_, w0, fmaf(m1_, w1, m2_ * w2));
+                    const float k0 = fmaf(m1_, w2, -(m2_ * w1)), k1 = fmaf(m2_, w0, -(m0_ * w2)), k2 = fmaf(m0_, w1, -(m1_ * w0));
+                    const float dp2 = fmaf(k0, k0, fmaf(k1, k1, k2 * k2));
+                    const float cn = (fabsf(m0_) + fabsf(m1_)) + fabsf(m2_);
+                    const float lim = fmaf(rb, 1.0f + kt, fmaxf(ta, 0.0f) * kt) + E + 4e-6f * cn;      // (w itself is off by RT_RHO)
+                    touch = touch && !(dp2 > lim * lim * 1.0001f) && !(ta < -(rb + E + 4e-6f * cn)) && !(ta > nv * (1.0f + kt) + rb + E + 4e-6f * cn);
+                    if (touch && e0 + (uint32_t)k <= e_last) mask |= 1u << k;
+                }
+                while (mask) {
+                    const int k = __builtin_ctz(mask);
+                    mask &= mask - 1u;
+                    const uint32_t pk = k == 0 ? lf4[0].pk : (k == 1 ? lf4[1].pk : (k == 2 ? lf4[2].pk : lf4[3].pk));
+                    const DPrim *pr = S.prims + (pk >> 2);
+                    int v;
+                    if ((pk & 3u) == 1u) {
+                        const double dx = pr->a[0] - P.x, dy = pr->a[1] - P.y, dz = pr->a[2] - P.z;
+                        const double cd = ((dx * dx + dy * dy) + dz * dz) - pr->b[0];
+                        v = sh_sphere((float)dx, (float)dy, (float)dz, (float)cd, w0, w1, w2, nvlim);
+                    } else {
+                        v = sh_box(__double2float_rd(pr->a[0] - P.x), __double2float_rd(pr->a[1] - P.y), __double2float_rd(pr->a[2] - P.z),
+                                   __double2float_ru(pr->b[0] - P.x), __double2float_ru(pr->b[1] - P.y), __double2float_ru(pr->b[2] - P.z), qi, nvlim);
+                    }
+                    verdict |= v;
+                    n_atp += v & SH_ATP;
+                    if (verdict & SH_OCCLUDE) return verdict;        // one certain occluder settles the ray
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        const uint2 t = stk[sp * STRIDE];
+        node = t.x;
+        unpack_lambda(t.y, l0, l1);
+    }
+    return verdict;
+}
