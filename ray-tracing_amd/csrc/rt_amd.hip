@@ -3,16 +3,23 @@
 // Wavefront pipeline, one recursion level of the reference's ray_tracing()
 // (ray_tracer.py:36-133) per iteration, no host synchronisation inside a frame:
 //
-//   k_gen        camera rays, one lane per pixel, 8x8 pixel tile per wave     (ray_functions.py:7-43)
 //   per level:
 //     k_intersect  nearest hit of every queued ray, miss -> background, hit -> compacted hit list
-//                                                                              (BSPNode.py:123-210)
-//     k_shadow     one lane per (hit, shadow light, a, b) soft-shadow ray, generated in registers,
-//                  lit bits reduced per (hit, light) with ballot/popcount       (Light.py:178-288)
+//                  (level 0 also makes the camera rays, 8x8 pixel tile per wave)    (ray_functions.py:7-43,
+//                                                                                BSPNode.py:123-210)
+//     soft shadows (Light.py:178-288), rt_shadow.hpp:
+//       k_beam_setup   one lane per (hit, light) pair: one beam traversal for all its s*s rays, whole-pair verdicts
+//       k_shadow_beam  one lane per ray of the pairs that need it: float32 filtered predicates on the pair's candidates
+//       k_shadow_walk  rays of pairs with too many candidates: each walks the tree itself, same predicates
+//       k_shadow_queue what the filters could not decide, in float64
+//       (k_shadow_setup + k_shadow: one float64 decision per ray, the diagnostic / fallback path)
 //     k_shade      Phong terms, framebuffer accumulation, reflection / transparency rays appended to
 //                  the next level's queue with a wave-level prefix sum          (Light.py:35-175,
 //                                                                               ray_tracer.py:77-132)
-//   k_resolve    clip + float32 / uint8 quantisation                           (ray_tracer.py:30, util.py:98)
+//   k_resolve    clip + float32 / uint8 quantisation (k_accumulate: the same over K frames)
+//                                                                              (ray_tracer.py:30, util.py:98)
+// enqueue_levels() lays the levels out over three streams (level 0's shadows | nearest hits of levels 1.. | their
+// shadows and shading); DESIGN.md section 5 and 8.
 //
 // The colour recursion  colour = through*T + (diff+spec)*(1-T) + refl*Kr  is linear in the child
 // colours, so each queued ray carries a throughput and adds throughput*local to its pixel.
