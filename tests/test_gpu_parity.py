@@ -454,3 +454,27 @@ def test_mixed_lattice_with_transparency_equals_exact_walk(oracle):
         assert np.array_equal(out["ids"], ref["ids"])
         assert np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
         assert out["stats"]["rays"] == ref["counters"]["rays"]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_scene_files_render_like_the_oracle(oracle, seed, tmp_path):
+    """Random scene files (tests/test_scene_native.py: several planes, lights between the surfaces so that ids and
+    list positions part ways (Q8), shadow intensities down to 0, cameras looking anywhere): text -> native tables,
+    host tree, then GPU frame == oracle frame (ids, 8-bit colours within 1, ray counters)."""
+    from test_scene_native import _random_scene_text, python_path
+    p = tmp_path / "scene.txt"
+    p.write_bytes(_random_scene_text(100 + seed).encode())
+    py = python_path(str(p))
+    ns = native.NativeScene(path=str(p))
+    ns.set_tree(py["bsp"].flat)
+    if ns.info["has_settings"] == 0:
+        prm = abi.render_params(64, 48, sh_rays=2 + seed % 3, rec_max=3, jitter=True, seed=seed)
+    else:
+        prm = abi.render_params(64, 48, rec_max=min(4, int(ns.desc.rec_max)), jitter=True, seed=seed)
+    ref = oracle.render(ns, prm)
+    with native.Context(ns) as ctx:
+        out = ctx.render(prm)
+    assert np.array_equal(out["ids"], ref["ids"])
+    assert np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
+    for key in ("primary_rays", "shadow_rays", "reflect_rays", "transmit_rays", "hits"):
+        assert out["stats"][key] == ref["counters"][key], key
