@@ -96,6 +96,7 @@ struct LevelParams {
     uint32_t spb, magic_s2, magic_s;     // magic_x = ceil(2^32 / x): n / x == __umulhi(n, magic_x) for n < 2^16
     int32_t beam;                        // this frame's soft shadows go through the beam path
     int32_t prio;                        // overlapped frame, deeper levels: raise the waves' issue priority
+    int32_t beam_early;                  // beam traversal near side first with the umbra test inside it (scenes with long beams)
     uint32_t walk_min;                   // rays of overflowing pairs: k_shadow_walk takes them when a level has at least this
                                          // many, else k_shadow_queue expands them (same verdicts either way)
 };
@@ -426,6 +427,7 @@ __device__ __forceinline__ void wave_append_flush(T *buf, uint32_t n, uint32_t *
 //   listed: header + candidate units go to rec[pair], the pair gets a slot in bb.list (wave-aggregated append);
 //   numerically delicate basis / too many candidates: listed with the overflow mark, all its rays go to the
 //     float64 queue.
+template <bool EARLY>
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) k_beam_setup(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb, BeamBuf bb,
                                                          FrameCtl *ctl) {
     extern __shared__ uint2 lds_stack[];
@@ -524,7 +526,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                     const float ur = fabsf(u0 * r0) + fabsf(u1 * r1) + fabsf(u2 * r2);
                     Q.aq = (0.5f * sm1 * g + g * (1.0f + ur)) * 1.0001f + 1e-5f;
                     Q.ja = (g * ((fabsf(u0) + fabsf(r0)) * fabsf(D0) + (fabsf(u1) + fabsf(r1)) * fabsf(D1) + (fabsf(u2) + fabsf(r2)) * fabsf(D2))) * 1.0001f + 1e-5f;
-                    bo = beam_collect<RT_BLOCK>(S, F, bs, tl_all + threadIdx.x, P, cB0, cB1, cB2, h0, h1, h2, Q, rec + 4, lp.flags);
+                    bo = beam_collect<RT_BLOCK, EARLY>(S, F, bs, tl_all + threadIdx.x, P, cB0, cB1, cB2, h0, h1, h2, Q, rec + 4, lp.flags);
                 }
             }
             if (lp.flags & 0x1000) {
@@ -1543,7 +1545,8 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow_queue, hipFuncAttributeMaxDynamicSharedMemorySize, big));
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow_walk, hipFuncAttributeMaxDynamicSharedMemorySize, big - 8192));   // 4 KB of static LDS (queue buffer)
-            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));   // 14 KB of static LDS (list buffer, touched entries)
+            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));   // 14 KB of static LDS (list buffer, touched entries)
+            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));
             HIP_C(hipFuncSetAttribute((const void *)&k_intersect_only<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         }
         if (getenv("RT_AMD_DEBUG")) fprintf(stderr, "[rt_amd] kd view: ok=%d depth=%d lds=%zu B\n", ctx->F.ok, max_depth, ctx->lds_bytes);
@@ -1569,7 +1572,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
         ctx->g_intersect_x = grid_for((const void *)&k_intersect<false, false>, 0);
         ctx->g_shadow = grid_for((const void *)&k_shadow<true>, lds); ctx->nb_shadow = last_nb;
         ctx->g_shadow_x = grid_for((const void *)&k_shadow<false>, 0);
-        ctx->g_beam_setup = grid_for((const void *)&k_beam_setup, lds); ctx->nb_beam_setup = last_nb;
+        ctx->g_beam_setup = grid_for((const void *)&k_beam_setup<false>, lds); ctx->nb_beam_setup = last_nb;
         ctx->g_beam = grid_for((const void *)&k_shadow_beam, 0); ctx->nb_beam = last_nb;
         ctx->g_queue = grid_for((const void *)&k_shadow_queue, lds); ctx->nb_queue = last_nb;
         ctx->g_walk = grid_for((const void *)&k_shadow_walk, lds); ctx->nb_walk = last_nb;
@@ -1835,6 +1838,10 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         const char *e = getenv("RT_AMD_WALK_MIN");
         const long long v = e ? atoll(e) : (3ll << 20);
         lp.walk_min = v < 0 || v > 0xfffffffell ? 0xffffffffu : (uint32_t)v;
+        // beams that cross many primitives before they leave the scene (large lattices under low lights): stop at the first
+        // sphere that covers the light.  Costs ~7 % on scenes whose beams are short; chosen by size, RT_AMD_BEAM_EARLY=0|1 overrides
+        const char *b = getenv("RT_AMD_BEAM_EARLY");
+        lp.beam_early = b ? (atoi(b) != 0) : (ctx->S.n_prims >= 100000);
     }
     dim3 block(RT_BLOCK);
     const bool prof = (p->flags & RT_FLAG_PROFILE) != 0;
@@ -1866,7 +1873,8 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         lp.last_level = (level == rec) ? 1 : 0;
         if (ctx->S.n_shadow_lights <= 0) return RT_OK;
         if (beam) {
-            hipLaunchKernelGGL(k_beam_setup, dim3(gsz(ctx->g_beam_setup, ctx->nb_beam_setup, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
+            if (lp.beam_early) hipLaunchKernelGGL(k_beam_setup<true>, dim3(gsz(ctx->g_beam_setup, ctx->nb_beam_setup, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
+            else hipLaunchKernelGGL(k_beam_setup<false>, dim3(gsz(ctx->g_beam_setup, ctx->nb_beam_setup, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
             hipLaunchKernelGGL(k_shadow_beam, dim3(gsz(ctx->g_beam, ctx->nb_beam, side == 1 ? 3 : side)), block, 0, s_, ctx->S, lp, hb, bb, ctx->ctl);
             if (lp.walk_min != 0xffffffffu)
                 hipLaunchKernelGGL(k_shadow_walk, dim3(gsz(ctx->g_walk, ctx->nb_walk, side == 1 ? 3 : side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, hb, bb, ctx->ctl);

@@ -225,7 +225,8 @@ struct BeamOut {
 //     cone;  b <= -bm for all rays: tau_out = -c / (|b| + sqrt(b^2 - c)), |tau_out| <= |c| / bm < 0.4e-6 -> AT_P;
 //     b >= bm for all rays: tau_out >= b >= bm > 1.1e-6 (the ray crosses P's own sphere) -> OCCLUDE.
 // The margins (1e-3 relative on the angles, bm = 1e-3 r) dwarf float32 and float64 rounding.
-template <int STRIDE>
+// EARLY (scenes with long beams): near side first, umbra test inside the traversal (see the loop).
+template <int STRIDE, bool EARLY>
 __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene &F, uint2 *stk, uint32_t *tl, d3 P, float cB0, float cB1,
                                                 float cB2, float h0, float h1, float h2, const LightQuad &Q, float4 *out, int dbg) {
     BeamOut R;
@@ -272,12 +273,19 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
             clip_mul(a0, a1, La, iLa, cut + E);          // left child: some beam point with x <= cut
             clip_mul(b0, b1, -Ua, -iUa, -(cut - E));     // right child: some beam point with x >= cut
             const bool goL = a0 <= a1, goR = b0 <= b1;
+            const uint32_t left = node + 1u, right = nd.b >> 2;
             if (goL && goR) {
-                stk[sp * STRIDE] = make_uint2(nd.b >> 2, pack_lambda(b0, b1));
+                // long beams: the side whose part of the beam starts nearer to P first - a sphere that hides the whole
+                // light from P (below) is usually met within a few leaves, and the rest of the beam is never walked.
+                // Short beams (the usual case) go left first and skip the test: there it costs more than it saves.
+                const bool left_first = !EARLY || a0 <= b0;
+                stk[sp * STRIDE] = left_first ? make_uint2(right, pack_lambda(b0, b1)) : make_uint2(left, pack_lambda(a0, a1));
                 ++sp;
-            }
-            if (goL) { node = node + 1; l0 = a0; l1 = a1; }
-            else if (goR) { node = nd.b >> 2; l0 = b0; l1 = b1; }
+                node = left_first ? left : right;
+                l0 = left_first ? a0 : b0;
+                l1 = left_first ? a1 : b1;
+            } else if (goL) { node = left; l0 = a0; l1 = a1; }
+            else if (goR) { node = right; l0 = b0; l1 = b1; }
             else { node = NONE; break; }
             nd = F.knodes[node];
         }
@@ -314,6 +322,20 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
                         const float cn = (fabsf(m0_) + fabsf(m1_)) + fabsf(m2_);      // >= |centre|
                         const float lim = fmaf(rb, 1.0f + kt, fmaxf(ta, 0.0f) * kt) + E + 2e-6f * cn;
                         in_cone = !(dp2 > lim * lim * 1.0001f) && !(ta < -(rb + E)) && !(ta > ax_len * (1.0f + kt) + rb + E);
+                        // A sphere well away from P that covers the whole cone (the umbra verdict of phase 2, with
+                        // |C|^2 - r^2 taken in float32: fine while it is >= 1 % of |C|^2): every ray is occluded, stop.
+                        if (EARLY && in_cone && sph) {
+                            const float cc = fmaf(c0, c0, fmaf(c1, c1, c2 * c2)), cf = cc - lf.r * lf.r;
+                            if (cf > 0.01f * cc && ta > 0.0f) {
+                                const float dp = __builtin_amdgcn_sqrtf(dp2), Cn = __builtin_amdgcn_sqrtf(cc);
+                                const float tb = lf.r * __builtin_amdgcn_rsqf(cf) * (1.0f - 1e-3f);
+                                const float num = fmaf(kt, ta, dp), den = fmaf(-kt, dp, ta);
+                                if (den > 0.0f && fmaf(num, 1.001f, 1e-6f * cn) < tb * den && (Cn + lf.r) * 1.0001f + 1e-4f < smin) {
+                                    R.occ_all = true;
+                                    return R;
+                                }
+                            }
+                        }
                     }
                     if (in_cone) {
                         const uint32_t prim = lf.pk >> 2;

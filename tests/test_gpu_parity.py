@@ -371,25 +371,28 @@ def test_schedules_with_fewer_buffer_sets_give_the_same_frames(gpu_ctx, env):
 
 
 @pytest.mark.parametrize("kind,sh,jitter", [("hard", 5, True), ("hard", 3, False), ("boxes", 5, True), ("boxes", 3, False),
-                                            ("inside", 4, True), ("original", 3, True), ("original", 4, False)])
+                                            ("inside", 4, True), ("original", 3, True), ("original", 4, False), ("wide", 5, True),
+                                            ("plain", 5, True), ("synth400", 5, True)])
 def test_rays_of_overflowing_pairs_walk_or_expand_to_the_same_frame(gpu_ctx, kind, sh, jitter):
     """Pairs whose beam meets more primitives than a pair record holds: their rays either walk the tree themselves with
     the float32 filtered predicates (k_shadow_walk, RT_AMD_WALK_MIN=1 forces it) or are expanded into the float64
     kernel (RT_AMD_WALK_MIN=-1).  Same frame bit for bit, and the same as the reference-order walk."""
-    ctx = gpu_ctx("original") if kind == "original" else _stress_ctx(kind)       # original.txt: every pair overflows
+    ctx = gpu_ctx(kind) if kind in ("original", "synth400") else _stress_ctx(kind)       # original.txt: every pair overflows
     prm = abi.render_params(160, 100, sh_rays=sh, rec_max=3, jitter=jitter, seed=9)
     exact = ctx.render(abi.render_params(160, 100, sh_rays=sh, rec_max=3, jitter=jitter, seed=9, flags=abi.RT_FLAG_EXACT_TRAVERSAL))
-    old = os.environ.get("RT_AMD_WALK_MIN")
+    old = {k: os.environ.get(k) for k in ("RT_AMD_WALK_MIN", "RT_AMD_BEAM_EARLY")}
     outs = {}
     try:
-        for v in ("1", "-1"):
+        for v, early in (("1", "0"), ("-1", "0"), ("1", "1"), ("-1", "1")):      # early: umbra test inside the beam traversal
             os.environ["RT_AMD_WALK_MIN"] = v
-            outs[v] = ctx.render(prm)
+            os.environ["RT_AMD_BEAM_EARLY"] = early
+            outs[v + early] = ctx.render(prm)
     finally:
-        if old is None:
-            os.environ.pop("RT_AMD_WALK_MIN", None)
-        else:
-            os.environ["RT_AMD_WALK_MIN"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     for out in outs.values():
         assert np.array_equal(out["ids"], exact["ids"]) and np.array_equal(out["rgb"], exact["rgb"])
         assert out["stats"]["rays"] == exact["stats"]["rays"]
