@@ -427,7 +427,7 @@ __device__ __forceinline__ void wave_append_flush(T *buf, uint32_t n, uint32_t *
 //   listed: header + candidate units go to rec[pair], the pair gets a slot in bb.list (wave-aggregated append);
 //   numerically delicate basis / too many candidates: listed with the overflow mark, all its rays go to the
 //     float64 queue.
-template <bool EARLY>
+template <bool EARLY, bool BOXES>
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) k_beam_setup(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb, BeamBuf bb,
                                                          FrameCtl *ctl) {
     extern __shared__ uint2 lds_stack[];
@@ -526,7 +526,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                     const float ur = fabsf(u0 * r0) + fabsf(u1 * r1) + fabsf(u2 * r2);
                     Q.aq = (0.5f * sm1 * g + g * (1.0f + ur)) * 1.0001f + 1e-5f;
                     Q.ja = (g * ((fabsf(u0) + fabsf(r0)) * fabsf(D0) + (fabsf(u1) + fabsf(r1)) * fabsf(D1) + (fabsf(u2) + fabsf(r2)) * fabsf(D2))) * 1.0001f + 1e-5f;
-                    bo = beam_collect<RT_BLOCK, EARLY>(S, F, bs, tl_all + threadIdx.x, P, cB0, cB1, cB2, h0, h1, h2, Q, rec + 4, lp.flags);
+                    bo = beam_collect<RT_BLOCK, EARLY, BOXES>(S, F, bs, tl_all + threadIdx.x, P, cB0, cB1, cB2, h0, h1, h2, Q, rec + 4, lp.flags);
                 }
             }
             if (lp.flags & 0x1000) {
@@ -1285,6 +1285,7 @@ struct rt_ctx {
     uint64_t last_slots = 0;
     int grid = 2048;
     int n_cu = 256;
+    int n_boxes = 0;
     int g_intersect = 2048, g_intersect_x = 2048, g_shadow = 2048, g_shadow_x = 2048, g_beam_setup = 2048, g_beam = 2048,
         g_queue = 2048, g_shade = 2048, g_setup = 2048;
 };
@@ -1409,6 +1410,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
     tick("context, stream, events");
     // ---- primitives: spheres first, then boxes ----
     const int ns = s->n_spheres, nb = s->n_boxes;
+    ctx->n_boxes = nb;
     std::vector<DPrim> prims((size_t)ns + nb);
     std::vector<FPrim> fprims((size_t)ns + nb);
     for (int i = 0; i < ns; ++i) {
@@ -1545,8 +1547,11 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow_queue, hipFuncAttributeMaxDynamicSharedMemorySize, big));
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow_walk, hipFuncAttributeMaxDynamicSharedMemorySize, big - 8192));   // 4 KB of static LDS (queue buffer)
-            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));   // 14 KB of static LDS (list buffer, touched entries)
-            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));
+            // 14 KB of static LDS (list buffer, touched entries)
+            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));
+            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));
+            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));
+            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));
             HIP_C(hipFuncSetAttribute((const void *)&k_intersect_only<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         }
         if (getenv("RT_AMD_DEBUG")) fprintf(stderr, "[rt_amd] kd view: ok=%d depth=%d lds=%zu B\n", ctx->F.ok, max_depth, ctx->lds_bytes);
@@ -1572,7 +1577,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
         ctx->g_intersect_x = grid_for((const void *)&k_intersect<false, false>, 0);
         ctx->g_shadow = grid_for((const void *)&k_shadow<true>, lds); ctx->nb_shadow = last_nb;
         ctx->g_shadow_x = grid_for((const void *)&k_shadow<false>, 0);
-        ctx->g_beam_setup = grid_for((const void *)&k_beam_setup<false>, lds); ctx->nb_beam_setup = last_nb;
+        ctx->g_beam_setup = grid_for((const void *)&k_beam_setup<false, true>, lds); ctx->nb_beam_setup = last_nb;
         ctx->g_beam = grid_for((const void *)&k_shadow_beam, 0); ctx->nb_beam = last_nb;
         ctx->g_queue = grid_for((const void *)&k_shadow_queue, lds); ctx->nb_queue = last_nb;
         ctx->g_walk = grid_for((const void *)&k_shadow_walk, lds); ctx->nb_walk = last_nb;
@@ -1873,8 +1878,15 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         lp.last_level = (level == rec) ? 1 : 0;
         if (ctx->S.n_shadow_lights <= 0) return RT_OK;
         if (beam) {
-            if (lp.beam_early) hipLaunchKernelGGL(k_beam_setup<true>, dim3(gsz(ctx->g_beam_setup, ctx->nb_beam_setup, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
-            else hipLaunchKernelGGL(k_beam_setup<false>, dim3(gsz(ctx->g_beam_setup, ctx->nb_beam_setup, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
+            {
+                // the kernel template that fits the scene: long beams or not, boxes or spheres only
+                const dim3 gs(gsz(ctx->g_beam_setup, ctx->nb_beam_setup, side));
+                const bool boxes = ctx->n_boxes > 0 || getenv("RT_AMD_BOX_KERNELS") != nullptr;
+                if (lp.beam_early && boxes) hipLaunchKernelGGL((k_beam_setup<true, true>), gs, block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
+                else if (lp.beam_early) hipLaunchKernelGGL((k_beam_setup<true, false>), gs, block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
+                else if (boxes) hipLaunchKernelGGL((k_beam_setup<false, true>), gs, block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
+                else hipLaunchKernelGGL((k_beam_setup<false, false>), gs, block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
+            }
             hipLaunchKernelGGL(k_shadow_beam, dim3(gsz(ctx->g_beam, ctx->nb_beam, side == 1 ? 3 : side)), block, 0, s_, ctx->S, lp, hb, bb, ctx->ctl);
             if (lp.walk_min != 0xffffffffu)
                 hipLaunchKernelGGL(k_shadow_walk, dim3(gsz(ctx->g_walk, ctx->nb_walk, side == 1 ? 3 : side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, hb, bb, ctx->ctl);

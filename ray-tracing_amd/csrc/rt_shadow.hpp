@@ -226,7 +226,8 @@ struct BeamOut {
 //     b >= bm for all rays: tau_out >= b >= bm > 1.1e-6 (the ray crosses P's own sphere) -> OCCLUDE.
 // The margins (1e-3 relative on the angles, bm = 1e-3 r) dwarf float32 and float64 rounding.
 // EARLY (scenes with long beams): near side first, umbra test inside the traversal (see the loop).
-template <int STRIDE, bool EARLY>
+// BOXES = false (scenes without boxes): every leaf entry is a sphere, the box arithmetic folds away.
+template <int STRIDE, bool EARLY, bool BOXES>
 __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene &F, uint2 *stk, uint32_t *tl, d3 P, float cB0, float cB1,
                                                 float cB2, float h0, float h1, float h2, const LightQuad &Q, float4 *out, int dbg) {
     BeamOut R;
@@ -301,7 +302,7 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
                 const LeafF lf = nxt;
                 nxt = F.leaves[e + 1u < e_end ? e + 1u : e];
                 ++R.trips;
-                const bool sph = (lf.pk & 3u) == 1u;     // sphere {centre, r, (low parts)}; box {lo, -, hi}
+                const bool sph = !BOXES || (lf.pk & 3u) == 1u;     // sphere {centre, r, (low parts)}; box {lo, -, hi}
                 const float rr = sph ? lf.r : 0.0f;
                 const float c0 = lf.x - Pf0, c1 = lf.y - Pf1, c2 = lf.z - Pf2;
                 const float d0 = sph ? c0 : lf.lx - Pf0, d1 = sph ? c1 : lf.ly - Pf1, d2 = sph ? c2 : lf.lz - Pf2;
@@ -364,7 +365,7 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
     for (uint32_t k = 0; k < nt; ++k) {
         const LeafF lf = F.leaves[F.prim_entry[tl[k * STRIDE]]];
         const uint32_t kind = lf.pk & 3u, prim = lf.pk >> 2;
-        const bool sph = kind == 1u;
+        const bool sph = !BOXES || kind == 1u;
         const float c0 = lf.x - Pf0, c1 = lf.y - Pf1, c2 = lf.z - Pf2;
         float ta = 0.0f, dp2 = 0.0f, cn = 0.0f;
         if (sph && cone_ok) {                        // (passed the cone test in phase 1)
