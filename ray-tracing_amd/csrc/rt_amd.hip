@@ -294,6 +294,8 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
     __shared__ uint32_t hbuf_all[(RT_BLOCK / 64) * (RT_HIT_RUN + 64)];      // per wave: up to RT_HIT_RUN - 1 parked hits + the 64 of one more chunk
     uint32_t *hbuf = hbuf_all + (threadIdx.x >> 6) * (RT_HIT_RUN + 64);
     uint32_t hn = 0u;
+    __shared__ uint32_t wcnt[2][RT_BLOCK / 64], wbase[2];      // GEN = false: per-chunk hit counts of the waves (two chunks in flight)
+    uint32_t it = 0u;
     while (walk.next(first)) {
         uint64_t k = first + threadIdx.x;
         bool active = k < n;
@@ -341,13 +343,20 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
         // they append per chunk.
         const unsigned long long mask = __ballot(has_hit);
         if (!GEN) {
-            if (mask) {
-                const int leader = __ffsll((long long)mask) - 1;
-                uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(&ctl->n_hits[lp.level], (uint32_t)__popcll(mask));
-                base = __shfl(base, leader);
-                if (has_hit) hb.list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)k;
+            // one atomic per workgroup and chunk (the four waves' counts meet in LDS; every wave of a workgroup walks the
+            // same chunks, so the barriers are reached by all)
+            const uint32_t par = it & 1u, wv = threadIdx.x >> 6;
+            ++it;
+            if (lane == 0) wcnt[par][wv] = (uint32_t)__popcll(mask);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const uint32_t tot = wcnt[par][0] + wcnt[par][1] + wcnt[par][2] + wcnt[par][3];
+                wbase[par] = tot ? atomicAdd(&ctl->n_hits[lp.level], tot) : 0u;
             }
+            __syncthreads();
+            uint32_t base = wbase[par];
+            for (uint32_t w = 0; w < wv; ++w) base += wcnt[par][w];
+            if (has_hit) hb.list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)k;
         } else if (mask) {
             if (has_hit) hbuf[hn + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)k;
             hn += (uint32_t)__popcll(mask);
@@ -1581,7 +1590,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
         if (ok) {
             // per-lane stacks can exceed the default 64 KB dynamic-LDS limit on deep trees
             const int big = 160 * 1024;
-            HIP_C(hipFuncSetAttribute((const void *)&k_intersect<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+            HIP_C(hipFuncSetAttribute((const void *)&k_intersect<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 1024));   // 40 B of static LDS
             HIP_C(hipFuncSetAttribute((const void *)&k_intersect<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 8192));   // 5 KB of static LDS (hit buffer)
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow_queue, hipFuncAttributeMaxDynamicSharedMemorySize, big));
