@@ -1032,6 +1032,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_queue(DScene S, FastScene F
 // lit counts, so level 1 can start while level 0's soft shadows are still being decided.
 #define RT_SHADE_LIGHTS 1
 #define RT_SHADE_SPAWN 2
+#define RT_SHADE_STORE 4     // level 0 of a frame: fb is this pass's own buffer and holds 0 at every hit's slot (k_intersect's
+                             // camera-ray pass), one hit per slot - a plain store replaces three float64 atomics per hit
 template <int MODE>
 __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, LevelParams lp, RayQ q, RayQ qn, HitBuf hb, FrameCtl *ctl,
                                                     double *fb, const unsigned long long *litbits, const uint32_t *pair_slot, const uint32_t *queue_n) {
@@ -1119,7 +1121,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, LevelParams lp, Ra
             spec = mk3(nan_to_num(spec.x), nan_to_num(spec.y), nan_to_num(spec.z));   // Light.py:173
             double nt = 1.0 - T;
             d3 base = (diff + spec) * mk3(nt, nt, nt);                   // ray_tracer.py:105-106
-            if (MODE & RT_SHADE_LIGHTS) fb_add(fb, slot, thr * base);
+            if (MODE & RT_SHADE_STORE) {
+                const d3 v = thr * base;
+                fb[3ull * slot] = v.x; fb[3ull * slot + 1] = v.y; fb[3ull * slot + 2] = v.z;
+            } else if (MODE & RT_SHADE_LIGHTS) fb_add(fb, slot, thr * base);
             if (!(MODE & RT_SHADE_SPAWN)) mflags = 0;
             if (mflags & 1) {                                            // ray_tracer.py:108-116
                 thr_t = thr * mk3(T, T, T);
@@ -1976,7 +1981,8 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
             PROF_MARK(e + 3);
             PROF_MARK(e + 4);
             if (level == 0) {
-                hipLaunchKernelGGL(k_shade<RT_SHADE_LIGHTS>, dim3(ctx->g_shade), block, 0, st, ctx->S, lp, qc, qn, hb, ctx->ctl, fb0, bb.litbits, bb.pair_slot, bb.queue_n);
+                if (fb0 != ctx->fb) hipLaunchKernelGGL((k_shade<RT_SHADE_LIGHTS | RT_SHADE_STORE>), dim3(ctx->g_shade), block, 0, st, ctx->S, lp, qc, qn, hb, ctx->ctl, fb0, bb.litbits, bb.pair_slot, bb.queue_n);
+                else hipLaunchKernelGGL(k_shade<RT_SHADE_LIGHTS>, dim3(ctx->g_shade), block, 0, st, ctx->S, lp, qc, qn, hb, ctx->ctl, fb0, bb.litbits, bb.pair_slot, bb.queue_n);
                 hipLaunchKernelGGL(k_shade<RT_SHADE_SPAWN>, dim3(ctx->g_shade), block, 0, st, ctx->S, lp, qc, qn, hb, ctx->ctl, ctx->fb, bb.litbits, bb.pair_slot, bb.queue_n);
             } else
                 hipLaunchKernelGGL(k_shade<3>, dim3(ctx->g_shade), block, 0, st, ctx->S, lp, qc, qn, hb, ctx->ctl, ctx->fb, bb.litbits, bb.pair_slot, bb.queue_n);
@@ -1990,7 +1996,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         // level 0 (caller's stream) is submitted first: the host needs ~10 us per launch, and the long chain of the
         // deeper levels must not delay the submission of the frame's largest kernel
         if (int rc = shadows(0, st, ctx->q[0], ctx->hb, ctx->seg, ctx->beam, 1)) return rc;
-        hipLaunchKernelGGL(k_shade<RT_SHADE_LIGHTS>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 3)), block, 0, st, ctx->S, lp, ctx->q[0], ctx->q[1], ctx->hb, ctx->ctl, fb0,
+        hipLaunchKernelGGL((k_shade<RT_SHADE_LIGHTS | RT_SHADE_STORE>), dim3(gsz(ctx->g_shade, ctx->nb_shade, 3)), block, 0, st, ctx->S, lp, ctx->q[0], ctx->q[1], ctx->hb, ctx->ctl, fb0,
                            ctx->beam.litbits, ctx->beam.pair_slot, ctx->beam.queue_n);
         // deeper levels (stream2): few, long rays - their waves ask for issue priority over the level-0 waves
         // (in frames of many million pixels the level-0 side is the long one and the priority only slows it down)
