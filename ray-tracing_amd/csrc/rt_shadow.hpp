@@ -363,10 +363,18 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
     // ---- phase 2: the touched primitives.  Whole-pair verdicts, float64 re-expression.
     uint32_t nu = 0, boxmask = 0;                    // units used, which units start a box
     for (uint32_t k = 0; k < nt; ++k) {
-        const LeafF lf = F.leaves[F.prim_entry[tl[k * STRIDE]]];
-        const uint32_t kind = lf.pk & 3u, prim = lf.pk >> 2;
+        // everything comes from the primitive's float64 record: ONE memory round trip per touched primitive (its
+        // float32 leaf record would cost two more, prim_entry -> leaves, in a loop that is bound by them)
+        const DPrim *pr = S.prims + tl[k * STRIDE];
+        const uint32_t kind = BOXES ? (uint32_t)pr->kind : 1u;
         const bool sph = !BOXES || kind == 1u;
-        const float c0 = lf.x - Pf0, c1 = lf.y - Pf1, c2 = lf.z - Pf2;
+        double dx = 0, dy = 0, dz = 0, cd = 0;
+        float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, lfr = 0.0f;
+        if (sph) {
+            dx = pr->a[0] - P.x; dy = pr->a[1] - P.y; dz = pr->a[2] - P.z;
+            c0 = (float)dx; c1 = (float)dy; c2 = (float)dz;
+            lfr = __double2float_ru(fabs(pr->b[1]));           // radius, rounded up like the leaf record's
+        }
         float ta = 0.0f, dp2 = 0.0f, cn = 0.0f;
         if (sph && cone_ok) {                        // (passed the cone test in phase 1)
             ta = fmaf(c0, ax0, fmaf(c1, ax1, c2 * ax2));
@@ -374,11 +382,8 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
             dp2 = fmaf(k0, k0, fmaf(k1, k1, k2 * k2));
             cn = (fabsf(c0) + fabsf(c1)) + fabsf(c2);                             // >= |c|
         }
-        const DPrim *pr = S.prims + prim;
         bool store = true;
-        double dx = 0, dy = 0, dz = 0, cd = 0;
         if (sph) {
-            dx = pr->a[0] - P.x; dy = pr->a[1] - P.y; dz = pr->a[2] - P.z;
             cd = ((dx * dx + dy * dy) + dz * dz) - pr->b[0];
             if (cone_ok) {                       // whole-pair verdict (see above)
                 // Every ray of the pair misses the sphere?  At the centre's axial depth ta the rays cross the
@@ -388,10 +393,10 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
                     const float tm = (ta + E) * __builtin_amdgcn_rcpf(ax_len - Q.ja) * 1.00001f * Q.aq + E;
                     const float cu = fabsf(fmaf(c0, Q.u0, fmaf(c1, Q.u1, c2 * Q.u2))), cr = fabsf(fmaf(c0, Q.r0, fmaf(c1, Q.r1, c2 * Q.r2)));
                     const float ex = fmaxf(cu - tm - 2e-6f * cn, 0.0f), ey = fmaxf(cr - tm - 2e-6f * cn, 0.0f);
-                    const float rl = fmaf(lf.r, fmaf(0.5f * kt, kt, 1.001f), E);
+                    const float rl = fmaf(lfr, fmaf(0.5f * kt, kt, 1.001f), E);
                     if (fmaf(ex, ex, ey * ey) > rl * rl) continue;
                 }
-                const float cf = (float)cd, rr = lf.r, dp = __builtin_amdgcn_sqrtf(dp2);
+                const float cf = (float)cd, rr = lfr, dp = __builtin_amdgcn_sqrtf(dp2);
                 const float Cn = __builtin_amdgcn_sqrtf(fmaf(c0, c0, fmaf(c1, c1, c2 * c2)));
                 const float bm = 1e-3f * rr;
                 const bool ends_before = (Cn + rr) * 1.0001f + 1e-4f < smin;
