@@ -215,6 +215,17 @@ int rt_trace(rt_ctx *ctx, const rt_render_params *p, const double *origins, cons
 int rt_intersect(rt_ctx *ctx, const double *origins, const double *directions, int64_t n, double *points_out,
                  int64_t *ids_out);
 
+/*
+ * The any-hit side of the same operator: the visibility test Light.compute_shadows applies to
+ * every shadow ray (Light.py:214-221).  lit_out[i] = 1 iff the nearest hit X of ray i = (origins[i], directions[i])
+ * (BSPNode.intersect_vectorize) satisfies ||X - targets[i]|| < 1e-6, else 0 (NaN anywhere -> 0).  Same verdicts as
+ * rt_intersect followed by that comparison on the host; the walk ends at the first float64-confirmed hit in front
+ * of the target and skips everything beyond it.  Rays as Light.get_shadow_rays makes them
+ * (direction = (target - origin) / (||target - origin|| + 1e-6)) are the fast case; any other batch is served too.
+ */
+int rt_visibility(rt_ctx *ctx, const double *origins, const double *directions, const double *targets, int64_t n,
+                  uint8_t *lit_out);
+
 /* Rank-0 side of the multi-GPU gather: scatter `world` packed per-rank tile
  * buffers (device memory, rank r at d_packed + r*stride_bytes) into a row-major
  * W*H*3 uint8 image on the device. */

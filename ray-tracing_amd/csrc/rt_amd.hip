@@ -1233,6 +1233,36 @@ __global__ void __launch_bounds__(RT_BLOCK) k_intersect_only(DScene S, FastScene
     }
 }
 
+// The any-hit query behind Light.compute_shadows (Light.py:214-221) for an arbitrary batch: ray k is "lit" iff the
+// nearest hit X of (o, d) lies within EPSILON of its target, |X - P| < 1e-6 (NaN -> unlit).  |X - P| >= | |P - o| -
+// |X - o| |, so nothing farther than |P - o| + 1e-6 can be that hit, and one float64-confirmed hit closer than
+// |P - o| - 3e-6 settles "unlit" whatever else lies on the ray: the walk ends there.  P need not lie on the ray.
+template <bool FAST>
+__device__ __forceinline__ bool ray_reaches(const DScene &S, const FastScene &F, uint2 *stk, d3 src, d3 dir, d3 P) {
+    if (FAST && ray_is_tame(src, dir)) {
+        const double nv = norm3(P - src), dn = norm3(dir);
+        if (nv < 1e7 && dn > 0.5 && dn < 2.0) {                      // ray parameter ~ distance: shadow rays are unit length
+            const float tP = __double2float_ru((nv + RT_EPSILON) / dn);
+            const float tlim = fmaf(tP, RT_2M20, tP + 1.6e-5f);
+            FastState st;
+            fast_nearest<RT_BLOCK>(S, F, stk, src, dir, tlim, nv - 3e-6, st);
+            if (st.stop) return false;
+            if (!st.tie) return norm3(st.best.p - P) < RT_EPSILON;
+        }
+    }
+    Hit x = nearest_hit_exact(S, src, dir);
+    return norm3(x.p - P) < RT_EPSILON;
+}
+
+template <bool FAST>
+__global__ void __launch_bounds__(RT_BLOCK) k_visibility(DScene S, FastScene F, const double *o, const double *d,
+                                                         const double *tg, uint64_t n, uint8_t *lit) {
+    extern __shared__ uint2 lds_stack[];
+    uint2 *stk = lds_stack + threadIdx.x;
+    for (uint64_t k = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x; k < n; k += (uint64_t)gridDim.x * RT_BLOCK)
+        lit[k] = ray_reaches<FAST>(S, F, stk, ld3(o + 3 * k), ld3(d + 3 * k), ld3(tg + 3 * k)) ? 1 : 0;
+}
+
 __global__ void k_deinterleave_u8(const uint8_t *packed, int64_t stride, uint8_t *image, int W, int H, int tw, int th,
                                   int tiles_x, int n_tiles, int world, int tiles_per_rank) {
     uint64_t total = (uint64_t)world * tiles_per_rank * tw * th;
@@ -1606,6 +1636,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
             HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));
             HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));
             HIP_C(hipFuncSetAttribute((const void *)&k_intersect_only<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+            HIP_C(hipFuncSetAttribute((const void *)&k_visibility<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         }
         if (getenv("RT_AMD_DEBUG")) fprintf(stderr, "[rt_amd] kd view: ok=%d depth=%d lds=%zu B\n", ctx->F.ok, max_depth, ctx->lds_bytes);
     }
@@ -2374,6 +2405,37 @@ extern "C" int rt_intersect(rt_ctx *ctx, const double *origins, const double *di
     TRY_I(hipMemcpy(points_out, d_p, vb, hipMemcpyDeviceToHost));
     TRY_I(hipMemcpy(ids_out, d_i, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost));
 #undef TRY_I
+    cleanup();
+    return RT_OK;
+}
+
+extern "C" int rt_visibility(rt_ctx *ctx, const double *origins, const double *directions, const double *targets,
+                             int64_t n, uint8_t *lit_out) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (!origins || !directions || !targets || !lit_out || n < 0) return fail(ctx, RT_ERR_INVALID_ARG, "NULL argument or negative n");
+    if (n == 0) return RT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    double *d_v = nullptr;           // origins | directions | targets
+    uint8_t *d_l = nullptr;
+    auto cleanup = [&]() {
+        if (d_v) (void)hipFree(d_v);
+        if (d_l) (void)hipFree(d_l);
+    };
+#define TRY_V(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+    const size_t vn = (size_t)n * 3, vb = vn * sizeof(double);
+    TRY_V(hipMalloc((void **)&d_v, 3 * vb));
+    TRY_V(hipMalloc((void **)&d_l, (size_t)n));
+    TRY_V(hipMemcpy(d_v, origins, vb, hipMemcpyHostToDevice));
+    TRY_V(hipMemcpy(d_v + vn, directions, vb, hipMemcpyHostToDevice));
+    TRY_V(hipMemcpy(d_v + 2 * vn, targets, vb, hipMemcpyHostToDevice));
+    if (ctx->F.ok && !getenv("RT_AMD_EXACT"))
+        hipLaunchKernelGGL(k_visibility<true>, dim3(ctx->grid), dim3(RT_BLOCK), ctx->lds_bytes, ctx->stream, ctx->S, ctx->F, d_v, d_v + vn, d_v + 2 * vn, (uint64_t)n, d_l);
+    else
+        hipLaunchKernelGGL(k_visibility<false>, dim3(ctx->grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->S, ctx->F, d_v, d_v + vn, d_v + 2 * vn, (uint64_t)n, d_l);
+    TRY_V(hipGetLastError());
+    TRY_V(hipStreamSynchronize(ctx->stream));
+    TRY_V(hipMemcpy(lit_out, d_l, (size_t)n, hipMemcpyDeviceToHost));
+#undef TRY_V
     cleanup();
     return RT_OK;
 }

@@ -229,3 +229,13 @@ class BSPNode:
             raise NotImplementedError("intersect_vectorize is served for the root of the tree")
         BSPNode.BSP_COUNTER += 1
         return self._context().intersect(ray_sources, ray_directions)
+
+    def direct_light_mask(self, ray_sources, ray_directions, targets):
+        """The any-hit form of the query, as Light.compute_shadows uses it (Light.py:214-221): (N,) bool,
+        True where the nearest hit of ray i lies within EPSILON of targets[i] - the same verdicts as
+        `norm(intersect_vectorize(...)[0] - targets, axis=-1) < EPSILON`, without finishing the walks
+        of occluded rays."""
+        if self is not self._root:
+            raise NotImplementedError("direct_light_mask is served for the root of the tree")
+        BSPNode.BSP_COUNTER += 1
+        return self._context().visibility(ray_sources, ray_directions, targets)

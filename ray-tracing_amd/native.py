@@ -16,7 +16,8 @@ LIB_PATH = os.path.join(_PKG, "csrc", "librt_amd.so")
 _LIB = None
 
 EXPORTS = ("rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_tile_pixels", "rt_tile_layout",
-           "rt_render", "rt_render_mean", "rt_render_device", "rt_sync_stats", "rt_trace", "rt_intersect", "rt_deinterleave_u8",
+           "rt_render", "rt_render_mean", "rt_render_device", "rt_sync_stats", "rt_trace", "rt_intersect", "rt_visibility",
+           "rt_deinterleave_u8",
            "rt_initial_rays", "rt_unit_prim_intersect", "rt_unit_prim_normals", "rt_unit_slab_mask",
            "rt_bsp_build", "rt_bsp_stats_get", "rt_bsp_fetch", "rt_bsp_destroy", "rt_bsp_last_error",
            "rt_scene_parse", "rt_scene_parse_file", "rt_scene_get_desc", "rt_scene_get_info", "rt_scene_corners",
@@ -52,6 +53,7 @@ def lib():
         L.rt_trace.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_void_p, C.POINTER(abi.Stats)]
         L.rt_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.rt_visibility.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.rt_deinterleave_u8.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_int64, C.c_void_p,
                                          C.c_void_p]
         L.rt_initial_rays.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -197,6 +199,17 @@ class Context:
         _check(lib().rt_intersect(self._h, o.ctypes.data, d.ctypes.data, o.shape[0], pts.ctypes.data,
                                   ids.ctypes.data), self._h)
         return pts, ids
+
+    def visibility(self, origins, directions, targets):
+        """The lit test of Light.compute_shadows (Light.py:214-221) for a ray batch: (N,) bool,
+        True where the nearest hit of ray i lies within 1e-6 of targets[i]."""
+        o, d, t = _f64(origins), _f64(directions), _f64(targets)
+        if not (o.shape == d.shape == t.shape) or o.ndim != 2 or o.shape[1] != 3:
+            raise ValueError("ray_sources/ray_directions/targets must all be (N,3)")
+        lit = np.empty(o.shape[0], dtype=np.uint8)
+        _check(lib().rt_visibility(self._h, o.ctypes.data, d.ctypes.data, t.ctypes.data, o.shape[0],
+                                   lit.ctypes.data), self._h)
+        return lit.astype(bool)
 
     def initial_rays(self, width, height):
         src = np.empty((width * height, 3))

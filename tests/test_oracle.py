@@ -84,6 +84,18 @@ def test_incoherent_rays(oracle, tag):
     assert np.allclose(pts, g["points"], rtol=1e-12, atol=1e-12, equal_nan=True)
 
 
+@pytest.mark.parametrize("tag", ["original", "small", "pool", "synth400"])
+def test_visibility_mask(oracle, tag):
+    """Light.py:214-221 on the reference's own jittered shadow rays: nearest hit within 1e-6 of the shaded point."""
+    g, meta = golden("visibility_" + tag)
+    pts, _, _ = oracle.intersect(load_scene(tag)["packed"], g["origins"], g["directions"])
+    targets = g["hits"][g["target_index"]]
+    with np.errstate(invalid="ignore"):
+        lit = np.linalg.norm(pts - targets, axis=-1) < 1e-6
+    assert 0 < meta["lit"] < meta["rays"]
+    assert np.array_equal(lit, g["lit"].astype(bool))
+
+
 FRAMES = ["pool_64x36_s1", "pool_160x90_s5", "pool_1920x1080_s1", "original_100x100", "original_500x500",
           "small_160x100", "small_64x40_s3_r6", "synth400_160x90_s2_r3"]
 

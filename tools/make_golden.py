@@ -324,6 +324,35 @@ def g_shadow_grid(out, scenes):
     save(out, "shadow_grid", None, **arrays)
 
 
+def g_visibility(out, scenes):
+    """The lit mask of Light.compute_shadows (Light.py:206-221) on jittered shadow rays of real hit points."""
+    for tag, w, h, s in (("pool", 32, 18, 3), ("original", 40, 40, 3), ("small", 40, 25, 3), ("synth400", 40, 22, 2)):
+        cam, st, surfaces, mats, lights, bsp = load_scene(scenes[tag])
+        src, dirs = ref_rf.get_initial_rays(cam, image_width=w, image_height=h)
+        with q4_mode(True):
+            pts, ids = bsp.intersect_vectorize(ray_sources=src, ray_directions=dirs)
+        hits = pts[ids != 0]
+        np.random.seed(77)
+        O, D, T, M = [], [], [], []
+        for light in lights:
+            if light.shadow_intensity == 0:
+                continue
+            L = ref_light_mod.compute_light_rays(hits, [light])[0]
+            ssrc, svec = ref_light_mod.get_shadow_rays(light, s, -L, hits)
+            n = hits.shape[0]
+            ssrc = ssrc.reshape((n * s * s, 3))
+            svec = svec.reshape((n * s * s, 3))
+            with q4_mode(True):
+                lh, _ = bsp.intersect_vectorize(ray_sources=ssrc, ray_directions=svec)
+            tg = np.tile(hits[:, np.newaxis, np.newaxis, :], (1, s, s, 1)).reshape((n * s * s, 3))
+            lit = np.linalg.norm(lh - tg, axis=-1) < ref_light_mod.EPSILON
+            O.append(ssrc); D.append(svec); T.append(np.repeat(np.arange(n, dtype=np.int32), s * s)); M.append(lit)
+            assert np.array_equal(hits[T[-1]], tg)
+        O, D, T, M = np.concatenate(O), np.concatenate(D), np.concatenate(T), np.concatenate(M)
+        save(out, "visibility_" + tag, dict(width=w, height=h, sh_rays=s, rays=int(len(M)), lit=int(M.sum())),
+             origins=O, directions=D, hits=hits, target_index=T, lit=M.astype(np.uint8))
+
+
 def g_shade_terms(out, scenes):
     rng = np.random.default_rng(4)
     n, Lc = 500, 3
@@ -446,7 +475,7 @@ def main():
         scenes[tag] = dst
 
     steps = dict(rays=g_rays, prims=g_prims, bsp=g_bsp, shadow_grid=g_shadow_grid, shade_terms=g_shade_terms,
-                 secondary=g_secondary, primary=g_primary, counts=g_counts,
+                 secondary=g_secondary, visibility=g_visibility, primary=g_primary, counts=g_counts,
                  frames=lambda o, s: g_frames(o, s, set(a.frames.split(",")) if a.frames else None),
                  stochastic=lambda o, s: g_stochastic(o, s, a.K))
     only = [x for x in a.only.split(",") if x]
