@@ -34,6 +34,8 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <atomic>
+#include <thread>
 
 #include "../../include/rt_amd.h"
 #include "rt_device.hpp"
@@ -1388,6 +1390,23 @@ static int fail(rt_ctx *ctx, int code, const std::string &msg) {
         }                                                                                                    \
     } while (0)
 
+// host loops of rt_create over millions of independent records: cut into contiguous pieces, one thread each
+// (nothing below 64 k records; at most 16 threads, the GPU box's CPU share)
+template <typename Fn>
+static void parallel_for(size_t n, Fn fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nt = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 16), n / 65536);
+    if (const char *e = getenv("RT_AMD_CREATE_THREADS")) nt = std::min<size_t>((size_t)std::max(atoi(e), 1), n ? n : 1);
+    if (nt <= 1) { fn((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    const size_t step = (n + nt - 1) / nt;
+    for (size_t t = 0; t < nt; ++t) {
+        const size_t b = t * step, e = std::min(n, b + step);
+        if (b < e) th.emplace_back([=]() { fn(b, e); });
+    }
+    for (auto &x : th) x.join();
+}
+
 template <typename T>
 static int upload(rt_ctx *ctx, std::vector<void *> &owner, const std::vector<T> &h, const T **out) {
     void *p = nullptr;
@@ -1496,28 +1515,32 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
     ctx->n_boxes = nb;
     std::vector<DPrim> prims((size_t)ns + nb);
     std::vector<FPrim> fprims((size_t)ns + nb);
-    for (int i = 0; i < ns; ++i) {
-        DPrim &p = prims[i];
-        memset(&p, 0, sizeof(p));
-        for (int k = 0; k < 3; ++k) p.a[k] = s->sph_center[3 * i + k];
-        p.b[0] = s->sph_r2[i]; p.b[1] = s->sph_radius[i]; p.b[2] = 0;
-        p.kind = 1; p.id = s->sph_id[i];
-        FPrim &f = fprims[i];
-        memset(&f, 0, sizeof(f));
-        for (int k = 0; k < 3; ++k) f.a[k] = (float)p.a[k];
-        f.r = round_up(fabs(s->sph_radius[i]));
-        f.kind = 1;
-    }
-    for (int i = 0; i < nb; ++i) {
-        DPrim &p = prims[(size_t)ns + i];
-        memset(&p, 0, sizeof(p));
-        for (int k = 0; k < 3; ++k) { p.a[k] = s->box_lo[3 * i + k]; p.b[k] = s->box_hi[3 * i + k]; }
-        p.kind = 2; p.id = s->box_id[i];
-        FPrim &f = fprims[(size_t)ns + i];
-        memset(&f, 0, sizeof(f));
-        for (int k = 0; k < 3; ++k) { f.a[k] = round_down(p.a[k]); f.b[k] = round_up(p.b[k]); }
-        f.kind = 2;
-    }
+    parallel_for((size_t)ns, [&](size_t b0, size_t e0) {
+        for (size_t i = b0; i < e0; ++i) {
+            DPrim &p = prims[i];
+            memset(&p, 0, sizeof(p));
+            for (int k = 0; k < 3; ++k) p.a[k] = s->sph_center[3 * i + k];
+            p.b[0] = s->sph_r2[i]; p.b[1] = s->sph_radius[i]; p.b[2] = 0;
+            p.kind = 1; p.id = s->sph_id[i];
+            FPrim &f = fprims[i];
+            memset(&f, 0, sizeof(f));
+            for (int k = 0; k < 3; ++k) f.a[k] = (float)p.a[k];
+            f.r = round_up(fabs(s->sph_radius[i]));
+            f.kind = 1;
+        }
+    });
+    parallel_for((size_t)nb, [&](size_t b0, size_t e0) {
+        for (size_t i = b0; i < e0; ++i) {
+            DPrim &p = prims[(size_t)ns + i];
+            memset(&p, 0, sizeof(p));
+            for (int k = 0; k < 3; ++k) { p.a[k] = s->box_lo[3 * i + k]; p.b[k] = s->box_hi[3 * i + k]; }
+            p.kind = 2; p.id = s->box_id[i];
+            FPrim &f = fprims[(size_t)ns + i];
+            memset(&f, 0, sizeof(f));
+            for (int k = 0; k < 3; ++k) { f.a[k] = round_down(p.a[k]); f.b[k] = round_up(p.b[k]); }
+            f.kind = 2;
+        }
+    });
     TRY_C(upload(ctx, ctx->scene_allocs, prims, &ctx->S.prims));
     TRY_C(upload(ctx, ctx->scene_allocs, fprims, &ctx->S.fprims));
 
@@ -1532,19 +1555,21 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
         // come later in the array, so a reverse sweep resolves them first
         for (int i = nn - 1; i >= 0; --i) skip[i] = s->node_right[i] < 0 ? i + 1 : skip[s->node_right[i]];
     }
-    for (int i = 0; i < nn; ++i) {
-        DNode &n = nodes[i];
-        for (int k = 0; k < 3; ++k) { n.lo[k] = s->node_lo[3 * i + k]; n.hi[k] = s->node_hi[3 * i + k]; }
-        n.skip = skip[i];
-        bool leaf = s->node_right[i] < 0;
-        n.first = leaf ? s->node_first[i] : -1;
-        n.count = leaf ? s->node_count[i] : 0;
-        n.pad = 0;
-        FNode &f = fnodes[i];
-        for (int k = 0; k < 3; ++k) { f.lo[k] = round_down(n.lo[k]); f.hi[k] = round_up(n.hi[k]); }
-        f.skip = skip[i];
-        f.first_count = !leaf ? -1 : ((n.first < (1 << 22) && n.count < 256) ? ((n.first << 8) | n.count) : -2);
-    }
+    parallel_for((size_t)nn, [&](size_t b0, size_t e0) {
+        for (size_t i = b0; i < e0; ++i) {
+            DNode &n = nodes[i];
+            for (int k = 0; k < 3; ++k) { n.lo[k] = s->node_lo[3 * i + k]; n.hi[k] = s->node_hi[3 * i + k]; }
+            n.skip = skip[i];
+            bool leaf = s->node_right[i] < 0;
+            n.first = leaf ? s->node_first[i] : -1;
+            n.count = leaf ? s->node_count[i] : 0;
+            n.pad = 0;
+            FNode &f = fnodes[i];
+            for (int k = 0; k < 3; ++k) { f.lo[k] = round_down(n.lo[k]); f.hi[k] = round_up(n.hi[k]); }
+            f.skip = skip[i];
+            f.first_count = !leaf ? -1 : ((n.first < (1 << 22) && n.count < 256) ? ((n.first << 8) | n.count) : -2);
+        }
+    });
     TRY_C(upload(ctx, ctx->scene_allocs, nodes, &ctx->S.nodes));
     TRY_C(upload(ctx, ctx->scene_allocs, fnodes, &ctx->S.fnodes));
     std::vector<int32_t> leaf(s->leaf_prim, s->leaf_prim + s->n_leaf_refs);
@@ -1592,22 +1617,29 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
         for (int e = s->n_leaf_refs - 1; e >= 0; --e) {           // (descending: prim_entry ends up with the first entry)
             const int p = s->leaf_prim[e];
             if (p >= 0 && p < ns + nb) prim_entry[p] = (uint32_t)e;
-            LeafF &f = lf[e];
-            memset(&f, 0, sizeof(f));
-            if (p < ns) {
-                const double *c = s->sph_center + 3 * p;
-                f.x = (float)c[0]; f.y = (float)c[1]; f.z = (float)c[2];
-                f.lx = (float)(c[0] - (double)f.x); f.ly = (float)(c[1] - (double)f.y); f.lz = (float)(c[2] - (double)f.z);
-                f.r = round_up(fabs(s->sph_radius[p]));
-                f.pk = ((uint32_t)p << 2) | 1u;
-                if (!(s->sph_r2[p] <= (double)f.r * (double)f.r * 1.0000001)) ok = false;   // r2 must be radius**2
-            } else {
-                const double *blo = s->box_lo + 3 * (p - ns), *bhi = s->box_hi + 3 * (p - ns);
-                f.x = round_down(blo[0]); f.y = round_down(blo[1]); f.z = round_down(blo[2]);
-                f.lx = round_up(bhi[0]); f.ly = round_up(bhi[1]); f.lz = round_up(bhi[2]);
-                f.pk = ((uint32_t)p << 2) | 2u;
-            }
         }
+        std::atomic<bool> r2_ok(true);
+        parallel_for((size_t)s->n_leaf_refs, [&](size_t b0, size_t e0) {
+            for (size_t e = b0; e < e0; ++e) {
+                const int p = s->leaf_prim[e];
+                LeafF &f = lf[e];
+                memset(&f, 0, sizeof(f));
+                if (p < ns) {
+                    const double *c = s->sph_center + 3 * (size_t)p;
+                    f.x = (float)c[0]; f.y = (float)c[1]; f.z = (float)c[2];
+                    f.lx = (float)(c[0] - (double)f.x); f.ly = (float)(c[1] - (double)f.y); f.lz = (float)(c[2] - (double)f.z);
+                    f.r = round_up(fabs(s->sph_radius[p]));
+                    f.pk = ((uint32_t)p << 2) | 1u;
+                    if (!(s->sph_r2[p] <= (double)f.r * (double)f.r * 1.0000001)) r2_ok = false;   // r2 must be radius**2
+                } else {
+                    const double *blo = s->box_lo + 3 * (size_t)(p - ns), *bhi = s->box_hi + 3 * (size_t)(p - ns);
+                    f.x = round_down(blo[0]); f.y = round_down(blo[1]); f.z = round_down(blo[2]);
+                    f.lx = round_up(bhi[0]); f.ly = round_up(bhi[1]); f.lz = round_up(bhi[2]);
+                    f.pk = ((uint32_t)p << 2) | 2u;
+                }
+            }
+        });
+        if (!r2_ok) ok = false;
         if ((size_t)ns + nb >= (1u << 30)) ok = false;
         TRY_C(upload(ctx, ctx->scene_allocs, kn, &ctx->F.knodes));
         TRY_C(upload(ctx, ctx->scene_allocs, lf, &ctx->F.leaves));
@@ -1681,15 +1713,17 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
     }
     TRY_C(upload(ctx, ctx->scene_allocs, planes, &ctx->S.planes));
     std::vector<DSurf> surfs(s->n_surfaces);
-    for (int i = 0; i < s->n_surfaces; ++i) {
-        DSurf &d = surfs[i];
-        memset(&d, 0, sizeof(d));
-        d.kind = s->surf_kind[i]; d.mat = s->surf_mat[i];
-        int g = s->surf_geom[i];
-        if (d.kind == RT_SURF_SPHERE) for (int k = 0; k < 3; ++k) d.p[k] = s->sph_center[3 * g + k];
-        if (d.kind == RT_SURF_BOX) { for (int k = 0; k < 3; ++k) d.p[k] = s->box_center[3 * g + k]; d.p[3] = s->box_scale[g]; }
-        if (d.kind == RT_SURF_PLANE) for (int k = 0; k < 3; ++k) d.p[k] = s->pln_normal[3 * g + k];
-    }
+    parallel_for((size_t)s->n_surfaces, [&](size_t b0, size_t e0) {
+        for (size_t i = b0; i < e0; ++i) {
+            DSurf &d = surfs[i];
+            memset(&d, 0, sizeof(d));
+            d.kind = s->surf_kind[i]; d.mat = s->surf_mat[i];
+            const size_t g = (size_t)s->surf_geom[i];
+            if (d.kind == RT_SURF_SPHERE) for (int k = 0; k < 3; ++k) d.p[k] = s->sph_center[3 * g + k];
+            if (d.kind == RT_SURF_BOX) { for (int k = 0; k < 3; ++k) d.p[k] = s->box_center[3 * g + k]; d.p[3] = s->box_scale[g]; }
+            if (d.kind == RT_SURF_PLANE) for (int k = 0; k < 3; ++k) d.p[k] = s->pln_normal[3 * g + k];
+        }
+    });
     TRY_C(upload(ctx, ctx->scene_allocs, surfs, &ctx->S.surfs));
     std::vector<DMat> mats(s->n_materials);
     for (int i = 0; i < s->n_materials; ++i) {
