@@ -210,16 +210,16 @@ def main():
         ms_shadow = prof["ms_shadow"]
         achieved = shadow_flops / (ms_shadow * 1e-3) / 1e12 if ms_shadow > 0 else 0.0
         # HBM-side traffic of the same kernels: a committed rocprofv3 --pmc measurement of this workload
-        # (tools/pmc_traffic.sh -> profiles/r01_j_traffic.json); counters cannot be read from inside this process
+        # (tools/pmc_traffic.sh -> profiles/r01_q_traffic.json); counters cannot be read from inside this process
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_j_traffic.json")
+        tfile = os.path.join(ROOT, "profiles", "r01_q_traffic.json")
         if args.workload == "synth10k" and world == 1 and (W, H) == (1920, 1080) and os.path.exists(tfile):
             with open(tfile) as f:
                 traffic = json.load(f)["soft_shadow_family"]["hbm_bytes_per_frame_upper"]
         roofline = {
             "bound": "valu", "kernel": "soft shadows: k_beam_setup + k_shadow_beam + k_shadow_queue", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": traffic,
-            "traffic_unit": "HBM bytes per frame of the soft-shadow kernels (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_j_traffic.json)",
+            "traffic_unit": "HBM bytes per frame of the soft-shadow kernels (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_q_traffic.json)",
             "achieved_is": "algorithmic flops of the reference's per-ray traversals / measured kernel time (DESIGN.md section 5)",
             "launches": prof["launches_per_family"], "kernel_ms_per_frame": round(ms_shadow, 3),
             "algorithmic_flops_per_shadow_ray": round(flops_per_shadow_ray, 1),
