@@ -80,8 +80,8 @@ def algorithmic_flops(cnt, n_lights, n_planes):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="synth10k")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--ingest", choices=("native", "python"), default="native",
                     help="scene text -> tables -> tree: C++ tokenizer + GPU tree build, or Python objects + host build")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-div", type=int, default=4, help="CPU baseline renders (W/div)x(H/div)")
+    ap.add_argument("--cpu-sample-div", type=int, default=2, help="CPU baseline renders (W/div)x(H/div)")
     args = ap.parse_args()
 
     import torch
