@@ -579,6 +579,13 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                     bo = beam_collect<RT_BLOCK, EARLY, BOXES>(S, F, bs, tl_all + threadIdx.x, P, cB0, cB1, cB2, h0, h1, h2, Q, rec + 4, lp.flags);
                 }
             }
+#ifdef RT_DEBUG_BEAM
+            if (lp.flags & 0x40000) {
+                printf("[setup] pair %u light %d P %.17g %.17g %.17g delicate %d overflow %d why %u occ_all %d atp_all %d nu %u boxmask %x pcls %x trips %u cB %g %g %g h %g %g %g\n", seg, m, P.x, P.y, P.z,
+                       (int)delicate, (int)bo.overflow, bo.why, (int)bo.occ_all, (int)bo.atp_all, bo.nu, bo.boxmask, pcls, bo.trips, cB0, cB1, cB2, h0, h1, h2);
+                for (uint32_t j = 0; j < RT_TOUCH; ++j) printf("[setup] touched[%u] = prim %u\n", j, tl_all[j * RT_BLOCK + threadIdx.x]);
+            }
+#endif
             if (lp.flags & 0x1000) {
                 atomicMax(&ctl->dbg_max_trips, bo.trips); atomicAdd(&ctl->dbg_sum_trips, (unsigned long long)bo.trips);
                 if (bo.overflow) atomicAdd(&ctl->dbg_why[delicate ? 0 : bo.why], 1u);
@@ -656,6 +663,10 @@ __device__ __forceinline__ bool shadow_ray_lit(const DScene &S, const FastScene 
         float tlim = fmaf(tP, RT_2M20, tP + 8e-6f);
         FastState st;
         fast_nearest<RT_BLOCK>(S, F, stk, src, dir, tlim, nv - 3e-6, st);
+#ifdef RT_DEBUG_BEAM
+        if (lp.flags & 0x40000) printf("[exact] pair %llu sample %u lit %d stop %d nearest id %d dist %.17g nv %.17g src %.17g %.17g %.17g\n", (unsigned long long)seg, kk,
+                                        (int)(!st.stop && (norm3(st.best.p - P) < RT_EPSILON)), (int)st.stop, st.best.id, st.best.dist, nv, src.x, src.y, src.z);
+#endif
         return !st.stop && (norm3(st.best.p - P) < RT_EPSILON);
     }
     Hit x = nearest_hit_exact(S, src, dir);
@@ -835,7 +846,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
                     if (k < S.n_planes) {
                         const uint32_t cls = (pcls >> (2 * k)) & 3u;
                         if (cls == RT_PLANE_EVAL) {
-                            const int v = sh_plane(pn[k][0], pn[k][1], pn[k][2], pdk[k], w0, w1, w2, nv, nvlim);
+                            const int v = sh_plane(pn[k][0], pn[k][1], pn[k][2], pdk[k], w0, w1, w2, nv, nvlim, S.plane_kw);
                             verdict |= v;
                             n_atp += v & SH_ATP;
                         } else n_atp += cls == RT_PLANE_ATP;
@@ -851,12 +862,15 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
                         v = sh_box(ua.x, ua.y, ua.z, ua.w, ub.x, ub.y, qi, nvlim);
                         j += 2;
                     } else {
-                        v = sh_sphere(ua.x, ua.y, ua.z, ua.w, w0, w1, w2, nvlim);
+                        v = sh_sphere(ua.x, ua.y, ua.z, ua.w, w0, w1, w2, nv, nvlim);
                         j += 1;
                     }
                     verdict |= v;
                     n_atp += v & SH_ATP;
                 }
+#ifdef RT_DEBUG_BEAM
+                if (lp.flags & 0x40000) printf("[beam] pair %u sample %u verdict %d n_atp %d nu %u nv %.9g w %.9g %.9g %.9g\n", seg, kk, verdict, n_atp, nu, nv, w0, w1, w2);
+#endif
                 if (verdict & SH_OCCLUDE) unsure = false;        // one certain occluder settles the ray
                 else if (verdict & SH_UNSURE) unsure = true;
                 else lit = n_atp > 0;
@@ -978,7 +992,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_walk(DScene S, FastScene F,
                     if (k < S.n_planes) {
                         const uint32_t cls = (pcls >> (2 * k)) & 3u;
                         if (cls == RT_PLANE_EVAL) {
-                            const int v = sh_plane(pn[k][0], pn[k][1], pn[k][2], pdk[k], w0, w1, w2, nv, nvlim);
+                            const int v = sh_plane(pn[k][0], pn[k][1], pn[k][2], pdk[k], w0, w1, w2, nv, nvlim, S.plane_kw);
                             verdict |= v;
                             n_atp += v & SH_ATP;
                         } else n_atp += cls == RT_PLANE_ATP;
@@ -1749,6 +1763,14 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
     ctx->S.n_prims = ns + nb; ctx->S.n_nodes = nn; ctx->S.n_planes = s->n_planes; ctx->S.n_surfs = s->n_surfaces;
     ctx->S.n_mats = s->n_materials; ctx->S.n_lights = s->n_lights; ctx->S.n_shadow_lights = (int)sl.size();
     ctx->S.far_clip = s->far_clip;
+    {
+        double kw = 0;
+        for (int i = 0; i < s->n_lights; ++i)
+            for (int k = 0; k < 3; ++k) kw = std::max(kw, fabs(s->lgt_pos[3 * i + k]) + 2.0 * fabs(s->lgt_radius[i]));
+        double dmax = 0;
+        for (int i = 0; i < s->n_planes; ++i) dmax = std::max(dmax, fabs(s->pln_d[i]));
+        ctx->S.plane_kw = round_up((kw + dmax) * 1.74);     // |o|_2 <= 1.74 |o|_inf
+    }
     for (int k = 0; k < 3; ++k) ctx->S.bg[k] = s->background[k];
     tick("surface / material / light tables");
     ctx->host = *s;   // pointers inside are NOT used after this call; scalars (camera, settings) are

@@ -91,6 +91,7 @@ struct DScene {
     const int32_t *shadow_lights;   // light indices with shadow_intensity != 0
     int32_t n_prims, n_nodes, n_planes, n_surfs, n_mats, n_lights, n_shadow_lights, far_clip;
     double bg[3];
+    float plane_kw;                 // >= |coordinate| of any light sample + |d| of any plane (sh_plane, rt_shadow.hpp)
 };
 
 struct Hit {

@@ -76,17 +76,27 @@ __device__ __forceinline__ int sh_classify(float lo, float hi, float nvlim) {
 
 // sphere {a = centre - P, c = |centre - P|^2 - r^2}.  With b = w.a and D = b^2 - c the light ray enters at
 // tau_out = b + sqrt(D); for b < 0 the stable form is  -c / (|b| + sqrt(D)).
-__device__ __forceinline__ int sh_sphere(float a0, float a1, float a2, float c, float w0, float w1, float w2, float nvlim) {
+// The verdict to reproduce is the REFERENCE's, and the reference evaluates its discriminant b'^2 - 4 a' c' from the
+// sample, R = |sample - centre| <= nv + |a| away (Sphere.py:63-107): float64 rounding of <= 84 * 2^-53 R^2 there, which
+// is nz = 2.4e-15 R^2 on D (a squared half chord) and moves its entry point by nz / (2 sqrt(D)).  Near a silhouette
+// that is no longer small against the 1e-6 of the lit test (R = 700: a line within a half chord of 7e-3 of grazing):
+// "hits" needs a half chord of gz = 1.5e-8 R^2 (entry point then within 0.8e-7 of the exact one, inside the margins of
+// sh_classify), "misses" needs D < -nz; everything between goes to the float64 queue, which repeats the reference's
+// arithmetic.
+__device__ __forceinline__ int sh_sphere(float a0, float a1, float a2, float c, float w0, float w1, float w2, float nv, float nvlim) {
     const float b = fmaf(w0, a0, fmaf(w1, a1, w2 * a2));
+    const float an1 = fabsf(a0) + fabsf(a1) + fabsf(a2);
+    const float Rb = nv + an1, R2 = Rb * Rb;
+    const float nz = 2.6e-15f * R2, gz = 1.5e-8f * R2;
     // clear miss, the common verdict: ed below is <= 1.1e-5 |a|^2 when D < 0 (then 0 <= c <= |a|^2)
-    if (fmaf(b, b, -c) < -1.5e-5f * fmaf(a0, a0, fmaf(a1, a1, a2 * a2))) return SH_MISS;
-    const float eb = RT_2M20 * (fabsf(w0 * a0) + fabsf(w1 * a1) + fabsf(w2 * a2)) + RT_RHO * (fabsf(a0) + fabsf(a1) + fabsf(a2));
+    if (fmaf(b, b, -c) < -1.5e-5f * fmaf(a0, a0, fmaf(a1, a1, a2 * a2)) - nz) return SH_MISS;
+    const float eb = RT_2M20 * (fabsf(w0 * a0) + fabsf(w1 * a1) + fabsf(w2 * a2)) + RT_RHO * an1;
     const float disc = fmaf(b, b, -c);
     const float ed = fmaf(2.0f * fabsf(b), eb, eb * eb) + 4.8e-7f * (b * b + fabsf(c));
-    const bool miss = disc < -ed;                                   // the line misses the sphere
-    const bool clear = disc > ed;                                   // else grazing
+    const bool miss = disc < -(ed + nz);                            // the line misses the sphere, for the reference too
     const float sl = __builtin_amdgcn_sqrtf(fmaxf(disc - ed, 0.0f)) * (1.0f - 6e-7f);
     const float sh = __builtin_amdgcn_sqrtf(disc + ed) * (1.0f + 6e-7f);
+    const bool clear = disc > ed && sl >= gz;                       // else grazing
     const float ab = fabsf(b);
     const float qa = (ab - eb) + sl, qb = (ab + eb) + sh;           // bounds of |b| + sqrt(D)
     const float cw = fabsf(c) * 4.8e-7f;
@@ -130,13 +140,15 @@ __device__ __forceinline__ int sh_box(float lo0, float lo1, float lo2, float hi0
     return !q.ok ? SH_UNSURE : miss ? SH_MISS : clean ? v : SH_UNSURE;
 }
 
-// plane: pd = n.P + d (float64, then rounded); tau = -pd / (w.n)
-__device__ __forceinline__ int sh_plane(float n0, float n1, float n2, float pd, float w0, float w1, float w2, float nv, float nvlim) {
+// plane: pd = n.P + d (float64, then rounded); tau = -pd / (w.n).  kw >= |coordinates of the sample| + |d|: the reference
+// divides o.n + d (float64 rounding <= 4 * 2^-53 kw) and nv-long ray parameters (relative 3 * 2^-53 / (w.n)) by w.n
+// (InfinitePlane.py:60-86); a verdict needs w.n large enough that both stay below 1e-7.
+__device__ __forceinline__ int sh_plane(float n0, float n1, float n2, float pd, float w0, float w1, float w2, float nv, float nvlim, float kw) {
     const float vn = fmaf(w0, n0, fmaf(w1, n1, w2 * n2));
-    const float ev = 2.5f * RT_RHO;                                 // |n|_1 <= 1.74, plus the rounding of n and the dot product
-    const bool back = vn < -ev;                                     // the light ray sees the back: one-sided (InfinitePlane.py:83)
+    const float ev = fmaxf(2.5f * RT_RHO, 5e-9f * (kw + nv));       // |n|_1 <= 1.74, plus the rounding of n and the dot product
+    const bool back = vn < -2.5f * RT_RHO;                          // the light ray sees the back: one-sided (InfinitePlane.py:83)
     const bool facing = vn > ev;
-    const float rp = __builtin_amdgcn_rcpf(vn + ev), rm = __builtin_amdgcn_rcpf(vn - ev);   // 1 ulp; covered by the 7e-7 below
+    const float rp = __builtin_amdgcn_rcpf(vn + 2.5f * RT_RHO), rm = __builtin_amdgcn_rcpf(vn - 2.5f * RT_RHO);   // 1 ulp; covered by the 7e-7 below
     const float num = -pd, nu = num * (1.0f + 4.8e-7f), nd = num * (1.0f - 4.8e-7f);
     const bool pos = num >= 0.0f;
     float lo = pos ? nd * rp : nu * rm, hi = pos ? nu * rm : nd * rp;
@@ -249,6 +261,7 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
     const bool cone_ok = rho2 < 0.25f;               // else: no cone culling, no whole-pair verdicts
     const float kt = cone_ok ? __builtin_amdgcn_sqrtf(rho2) * __builtin_amdgcn_rsqf(1.0f - rho2) * 1.0001f : 1e30f;
     const float smin = (ax_len - __builtin_amdgcn_sqrtf(hh2) * 1.000001f) * (1.0f - 1e-6f);   // <= |sample| for every sample
+    const float smaxv = (ax_len + __builtin_amdgcn_sqrtf(hh2) * 1.000001f) * (1.0f + 1e-6f);  // >= |sample| for every sample
     float l0 = 0.0f, l1 = 1.0f;
     // root box relative to P
     clip_mul(l0, l1, -U0, -iU0, -((F.root_lo[0] - Pf0) - E)); clip_mul(l0, l1, L0, iL0, (F.root_hi[0] - Pf0) + E);
@@ -308,7 +321,12 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
                 const float d0 = sph ? c0 : lf.lx - Pf0, d1 = sph ? c1 : lf.ly - Pf1, d2 = sph ? c2 : lf.lz - Pf2;
                 const bool touch = !(c0 - rr > bhi0) && !(d0 + rr < blo0) && !(c1 - rr > bhi1) && !(d1 + rr < blo1) &&
                                    !(c2 - rr > bhi2) && !(d2 + rr < blo2);
-                if (touch) {
+#ifdef RT_DEBUG_BEAM
+                const bool touch_dbg = touch || (dbg & 0x20000);
+#else
+                const bool touch_dbg = touch;
+#endif
+                if (touch_dbg) {
                     bool in_cone = true;
                     if (cone_ok) {
                         // sphere (a box: its bounding sphere) against the cone: distance to the axis <= r (1 + tan) +
@@ -338,6 +356,9 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
                             }
                         }
                     }
+#ifdef RT_DEBUG_BEAM
+                    if (dbg & 0x8000) in_cone = true;
+#endif
                     if (in_cone) {
                         const uint32_t prim = lf.pk >> 2;
                         bool seen = false;               // a primitive is listed in every leaf it reaches into
@@ -394,11 +415,17 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
                     const float cu = fabsf(fmaf(c0, Q.u0, fmaf(c1, Q.u1, c2 * Q.u2))), cr = fabsf(fmaf(c0, Q.r0, fmaf(c1, Q.r1, c2 * Q.r2)));
                     const float ex = fmaxf(cu - tm - 2e-6f * cn, 0.0f), ey = fmaxf(cr - tm - 2e-6f * cn, 0.0f);
                     const float rl = fmaf(lfr, fmaf(0.5f * kt, kt, 1.001f), E);
+#ifdef RT_DEBUG_BEAM
+                    if (!(dbg & 0x4000))
+#endif
                     if (fmaf(ex, ex, ey * ey) > rl * rl) continue;
                 }
                 const float cf = (float)cd, rr = lfr, dp = __builtin_amdgcn_sqrtf(dp2);
                 const float Cn = __builtin_amdgcn_sqrtf(fmaf(c0, c0, fmaf(c1, c1, c2 * c2)));
-                const float bm = 1e-3f * rr;
+                // (the reference's own rounding at a silhouette, see sh_sphere: a whole-pair verdict on P's own sphere needs
+                // every ray's half chord |b| above 1.5e-8 R^2, R <= max |sample| + r)
+                const float Rw = smaxv + rr;
+                const float bm = fmaxf(1e-3f * rr, 1.5e-8f * Rw * Rw);
                 const bool ends_before = (Cn + rr) * 1.0001f + 1e-4f < smin;
                 const float num = fmaf(kt, ta, dp), den = fmaf(-kt, dp, ta);       // dp + kt ta,  ta - kt dp
                 if (cf > 1e-4f * rr * rr) {
@@ -433,6 +460,9 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
                     const float cu = fabsf(fmaf(m0_, Q.u0, fmaf(m1_, Q.u1, m2_ * Q.u2))), cr = fabsf(fmaf(m0_, Q.r0, fmaf(m1_, Q.r1, m2_ * Q.r2)));
                     const float ex = fmaxf(cu - tm - 2e-6f * cnb, 0.0f), ey = fmaxf(cr - tm - 2e-6f * cnb, 0.0f);
                     const float rl = fmaf(rb, fmaf(0.5f * kt, kt, 1.001f), E);
+#ifdef RT_DEBUG_BEAM
+                    if (!(dbg & 0x4000))
+#endif
                     if (fmaf(ex, ex, ey * ey) > rl * rl) continue;
                 }
                 const float smax = ax_len + __builtin_amdgcn_sqrtf(hh2) * 1.000001f;            // >= |sample|
@@ -568,7 +598,7 @@ __device__ __forceinline__ int ray_walk(const DScene &S, const FastScene &F, uin
                     if ((pk & 3u) == 1u) {
                         const double dx = pr->a[0] - P.x, dy = pr->a[1] - P.y, dz = pr->a[2] - P.z;
                         const double cd = ((dx * dx + dy * dy) + dz * dz) - pr->b[0];
-                        v = sh_sphere((float)dx, (float)dy, (float)dz, (float)cd, w0, w1, w2, nvlim);
+                        v = sh_sphere((float)dx, (float)dy, (float)dz, (float)cd, w0, w1, w2, nv, nvlim);
                     } else {
                         v = sh_box(__double2float_rd(pr->a[0] - P.x), __double2float_rd(pr->a[1] - P.y), __double2float_rd(pr->a[2] - P.z),
                                    __double2float_ru(pr->b[0] - P.x), __double2float_ru(pr->b[1] - P.y), __double2float_ru(pr->b[2] - P.z), qi, nvlim);

@@ -81,3 +81,36 @@ def test_eight_ranks_reassemble_the_full_frame(bench_scene, full_frame):
         rays += out["stats"]["rays"]
     assert np.array_equal(image, full_frame["rgb8"].reshape(-1, 3))
     assert rays == full_frame["stats"]["rays"]
+
+
+# ---- BASELINE.json configs[4]: one million mixed spheres / boxes with transparency and reflection, recursion 10 ----
+@pytest.fixture(scope="module")
+def lattice_scene():
+    sys.path.insert(0, ROOT)
+    import bench
+    scene, _ = bench.build_scene("synth1M")
+    ctx = native.Context(scene.packed, device=0)
+    yield scene, ctx
+    ctx.close()
+
+
+def test_million_primitive_scene_fast_path_equals_exact_walk_and_oracle(lattice_scene, oracle):
+    """Reduced resolution, full scene: the long-beam templates, k_shadow_walk and the float64 queue all carry rays
+    here.  Default path == float64 reference-order walk bit for bit; one rank of an 8-way partition == oracle."""
+    scene, ctx = lattice_scene
+    assert scene.packed.desc.n_spheres + scene.packed.desc.n_boxes == 1_000_000
+    w, h = 320, 180
+    kw = dict(sh_rays=3, rec_max=10, jitter=True, seed=77)
+    fast = ctx.render(abi.render_params(w, h, **kw))
+    exact = ctx.render(abi.render_params(w, h, flags=abi.RT_FLAG_EXACT_TRAVERSAL, **kw))
+    assert np.array_equal(fast["ids"], exact["ids"])
+    assert fast["stats"]["rays"] == exact["stats"]["rays"]
+    assert fast["stats"]["transmit_rays"] > 0 and fast["stats"]["reflect_rays"] > 0
+    assert np.array_equal(fast["rgb"], exact["rgb"])
+    p = abi.render_params(w, h, rank=3, world=8, **kw)
+    out = ctx.render(p)
+    ref = oracle.render(scene.packed, p, threads=min(16, os.cpu_count() or 1))
+    assert np.array_equal(out["ids"], ref["ids"])
+    assert np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
+    for key in ("primary_rays", "shadow_rays", "reflect_rays", "transmit_rays", "hits"):
+        assert out["stats"][key] == ref["counters"][key], key
