@@ -114,3 +114,24 @@ def test_million_primitive_scene_fast_path_equals_exact_walk_and_oracle(lattice_
     assert np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
     for key in ("primary_rays", "shadow_rays", "reflect_rays", "transmit_rays", "hits"):
         assert out["stats"][key] == ref["counters"][key], key
+
+
+# ---- every error bound of the float32 filters has to scale with the scene ----
+@pytest.mark.parametrize("tag,k", [("small", 0.001), ("small", 1000.0), ("original", 0.03), ("synth400", 40.0),
+                                   ("pool", 1000.0), ("synth400", 0.001)])
+def test_scaled_scenes_match_exact_walk_and_oracle(oracle, tag, k):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from check_beam_vs_exact import scaled
+    from conftest import scene_path
+    from ray_tracing_amd.render import FastScene
+    sc = FastScene(text=scaled(open(scene_path(tag)).read(), k))
+    with native.Context(sc.packed, device=0) as ctx:
+        p = dict(sh_rays=3, rec_max=6, jitter=True, seed=3)
+        fast = ctx.render(abi.render_params(240, 136, **p))
+        exact = ctx.render(abi.render_params(240, 136, flags=abi.RT_FLAG_EXACT_TRAVERSAL, **p))
+    ref = oracle.render(sc.packed, abi.render_params(240, 136, **p), threads=min(16, os.cpu_count() or 1))
+    assert np.array_equal(fast["ids"], exact["ids"]) and np.array_equal(fast["rgb"], exact["rgb"])
+    assert np.array_equal(fast["ids"], ref["ids"])
+    assert np.abs(fast["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
+    for key in ("primary_rays", "shadow_rays", "reflect_rays", "transmit_rays", "hits"):
+        assert fast["stats"][key] == ref["counters"][key], key
