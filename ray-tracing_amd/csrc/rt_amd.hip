@@ -54,7 +54,7 @@ struct FrameCtl {
     uint32_t n_rays[RT_MAX_LEVELS + 2];
     uint32_t n_hits[RT_MAX_LEVELS + 2];
     uint32_t overflow;
-    uint32_t pad;
+    uint32_t overflow_q;                    // ... and it was the float64 shadow-ray queue (bb.queue) that ran out
     unsigned long long reflect_rays, transmit_rays, primary_rays;
     uint32_t n_listed[RT_MAX_LEVELS + 2];   // diagnostics: pairs that needed the per-ray filter / rays that needed
     uint32_t n_queued[RT_MAX_LEVELS + 2];   // the float64 queue, per level (copied by k_shade)
@@ -891,7 +891,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
                 base = __shfl(base, 0);
                 const unsigned long long v = qbuf[lane], v2 = qbuf[64 + lane];
                 if (base + (uint32_t)lane < queue_cap) bb.queue[base + (uint32_t)lane] = v;
-                else ctl->overflow = 1;             // frame is void; the host re-renders with a larger queue
+                else ctl->overflow = ctl->overflow_q = 1u;             // frame is void; the host re-renders with a larger queue
                 qn -= 64u;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
@@ -917,7 +917,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
         base = __shfl(base, 0);
         if ((uint32_t)lane < qn) {
             if (base + (uint32_t)lane < queue_cap) bb.queue[base + (uint32_t)lane] = qbuf[lane];
-            else ctl->overflow = 1;
+            else ctl->overflow = ctl->overflow_q = 1u;
         }
     }
 }
@@ -940,7 +940,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_walk(DScene S, FastScene F,
     uint32_t qn = 0u;
     auto store_q = [&](uint32_t slot, unsigned long long v) {
         if (slot < queue_cap) bb.queue[slot] = v;
-        else ctl->overflow = 1;                       // frame is void; the host re-renders with a larger queue
+        else ctl->overflow = ctl->overflow_q = 1u;                       // frame is void; the host re-renders with a larger queue
     };
     float pn[RT_PMAX][3];
     for (int k = 0; k < RT_PMAX; ++k)
@@ -1357,6 +1357,7 @@ struct rt_ctx {
     uint64_t fb_slots = 0;
     uint64_t fb_slots_frame = 0;   // primary slots of the frame being enqueued
     double growth = 2.0;    // queue capacity = growth * primary slots
+    double qgrowth = 1.0;   // float64 shadow-ray queue = qgrowth * queue capacity (grows by itself: large s, many undecided rays)
     std::vector<void *> frame_allocs;
     RayQ q[4]{};            // level 0 -> q[0]; level k >= 1 -> q[1 + (k - 1) % 2] (% 3 when the deeper levels are pipelined)
     HitBuf hb{}, hb1{}, hb2{};   // level 0 / deeper levels, odd / deeper levels, even (so are seg*, beam*)
@@ -1826,7 +1827,9 @@ static int dalloc(rt_ctx *ctx, T **p, uint64_t n) {
 static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
     uint64_t want_cap = (uint64_t)((double)slots * ctx->growth) + 1024;
     if (want_cap > 0xFFFFFFF0ull) return fail(ctx, RT_ERR_UNSUPPORTED, "ray queue would exceed 2^32 entries");
-    if (ctx->cap >= want_cap && ctx->fb_slots >= slots) return RT_OK;
+    const double want_qd = (double)want_cap * ctx->qgrowth;
+    const uint32_t want_q = (uint32_t)(want_qd < 2147483647.0 ? want_qd : 2147483647.0);
+    if (ctx->cap >= want_cap && ctx->fb_slots >= slots && ctx->beam_queue_cap >= want_q) return RT_OK;
     HIP_TRY(ctx, hipDeviceSynchronize());   // rare: buffers of an in-flight frame are about to be replaced
     free_frame(ctx);
     uint64_t cap = want_cap;
@@ -1839,7 +1842,7 @@ static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
         TRY_A(dalloc(ctx, &q.slot, cap)); TRY_A(dalloc(ctx, &q.gpix, cap)); TRY_A(dalloc(ctx, &q.path, cap));
     }
     uint64_t nlit = cap * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1);
-    ctx->beam_queue_cap = (uint32_t)(cap < 0x7fffffffull ? cap : 0x7fffffffull);
+    ctx->beam_queue_cap = want_q;
     ctx->two_sets = true;
     ctx->three_sets = true;
     for (int set = 0; set < 3; ++set) {          // level 0 / deeper levels (odd, even): the parts of an overlapped frame
@@ -2279,7 +2282,9 @@ extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
         }
     }
     if (c.overflow) {
-        ctx->growth *= 2.0;   // the next frame gets larger queues
+        // the next frame gets larger queues: the one that ran out
+        if (c.overflow_q && ctx->beam_queue_cap < 0x7fffffffu) ctx->qgrowth *= 8.0;
+        else ctx->growth *= 2.0;
         return fail(ctx, RT_ERR_QUEUE_OVERFLOW, "secondary-ray queue overflow; queue growth factor doubled, render again");
     }
     return RT_OK;
@@ -2305,7 +2310,7 @@ extern "C" int rt_render(rt_ctx *ctx, const rt_render_params *p, float *rgb_out,
     if (rgb_out) TRY_R(hipMalloc((void **)&d_rgb, g.out_slots * 3 * sizeof(float)));
     if (rgb8_out || !rgb_out) TRY_R(hipMalloc((void **)&d_rgb8, g.out_slots * 3));
     if (ids_out) TRY_R(hipMalloc((void **)&d_ids, g.out_slots * sizeof(int32_t)));
-    for (int attempt = 0; attempt < 6; ++attempt) {
+    for (int attempt = 0; attempt < 10; ++attempt) {
         rc = rt_render_device(ctx, p, d_rgb, d_rgb8, d_ids, nullptr);
         if (rc != RT_OK) break;
         rc = rt_sync_stats(ctx, stats);
@@ -2352,7 +2357,7 @@ extern "C" int rt_render_mean(rt_ctx *ctx, const rt_render_params *p, int32_t fr
         rt_render_params q = *p;
         q.seed = p->seed + (uint32_t)k;                       // frame k of the mean = the frame rt_render gives for seed + k
         rt_stats st;
-        for (int attempt = 0; attempt < 6; ++attempt) {
+        for (int attempt = 0; attempt < 10; ++attempt) {
             rc = rt_render_device(ctx, &q, nullptr, nullptr, nullptr, nullptr);
             if (rc != RT_OK) break;
             rc = rt_sync_stats(ctx, &st);
@@ -2400,7 +2405,7 @@ extern "C" int rt_trace(rt_ctx *ctx, const rt_render_params *p, const double *or
     TRY_T(hipMalloc((void **)&d_d, (size_t)n * 3 * sizeof(double)));
     TRY_T(hipMemcpy(d_o, origins, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice));
     TRY_T(hipMemcpy(d_d, directions, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice));
-    for (int attempt = 0; attempt < 6; ++attempt) {
+    for (int attempt = 0; attempt < 10; ++attempt) {
         rc = ensure_frame(ctx, (uint64_t)n);
         if (rc != RT_OK) break;
         TRY_T(hipEventRecord(ctx->ev0, st));

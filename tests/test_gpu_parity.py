@@ -210,6 +210,22 @@ def test_tile_partition_reassembles_bit_identical(gpu_ctx):
     assert np.array_equal(img, full["rgb8"])
 
 
+def test_large_shadow_grids_grow_the_float64_queue(gpu_ctx):
+    """16 x 16 shadow rays on the box-crowded scene: most pairs leave the filter undecided, 256 rays each - the float64
+    queue has to grow on its own (the ray queues do not), and the frame equals the exact walk."""
+    from ray_tracing_amd import native as nat
+    ctx = nat.Context(load_scene("original")["packed"], device=0)      # a fresh context: queue sizes at their defaults
+    try:
+        p = dict(sh_rays=16, rec_max=3, jitter=True, seed=9)
+        fast = ctx.render(abi.render_params(96, 96, **p))
+        exact = ctx.render(abi.render_params(96, 96, flags=abi.RT_FLAG_EXACT_TRAVERSAL, **p))
+    finally:
+        ctx.close()
+    assert fast["stats"]["shadow_rays"] > 96 * 96 * 256
+    assert np.array_equal(fast["ids"], exact["ids"])
+    assert np.array_equal(fast["rgb"], exact["rgb"])
+
+
 # ------------------------------------------------------------------ error behaviour of the boundary
 def test_bad_arguments_are_reported(gpu_ctx):
     ctx = gpu_ctx("pool")

@@ -20,7 +20,7 @@ def make_scene(rng):
     cam_d = ext * rng.uniform(1.2, 3.0)
     L.append("cam %r %r %r 0 0 0 0 1 0 %r 1" % (float(rng.uniform(-0.3, 0.3) * cam_d), float(rng.uniform(0.2, 0.9) * cam_d),
                                                float(-cam_d), float(rng.uniform(0.8, 2.0))))
-    sh = int(rng.choice([3, 3, 4, 5, 7]))
+    sh = int(rng.choice([3, 3, 4, 5, 7, 11, 16, 17, 2, 1]))
     L.append("set %r %r %r %d %d" % (0.2, 0.3, 0.5, sh, int(rng.integers(0, 7))))
     n_mtl = 6
     for m in range(n_mtl):
