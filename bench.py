@@ -104,10 +104,18 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the hot path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # RT_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share GPUs,
+    # the gather is staged through host memory); the measured configuration is nccl = RCCL, one GPU per rank
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    gpu_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     import ray_tracing_amd  # noqa: F401
     from ray_tracing_amd import abi, native
@@ -115,10 +123,10 @@ def main():
 
     if args.ingest == "native":      # code objects loaded and the HIP context up before ingestion is timed
         import numpy as np
-        native.bsp_build(np.zeros((4, 3)), np.ones((4, 3)), device=local_rank)
-    scene, ingest_s = build_scene(args.workload, args.ingest, local_rank)
+        native.bsp_build(np.zeros((4, 3)), np.ones((4, 3)), device=gpu_index)
+    scene, ingest_s = build_scene(args.workload, args.ingest, gpu_index)
     t_up = time.perf_counter()
-    ctx = native.Context(scene.packed, device=local_rank)
+    ctx = native.Context(scene.packed, device=gpu_index)
     upload_s = time.perf_counter() - t_up
     W = args.width or (1920 if world == 1 else 3840)
     H = args.height or (1080 if world == 1 else 2160)
@@ -168,8 +176,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     st = ctx.sync_stats()                       # counters of the last frame (ray counts do not depend on the seed)
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    rays = torch.tensor([float(st["rays"])], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    rays = torch.tensor([float(st["rays"])], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
@@ -192,7 +200,7 @@ def main():
         # reference's algorithm (nodes visited, primitives tested) are resolution independent
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import orc
-        div = max(1, args.cpu_sample_div)
+        div = max(1, args.cpu_sample_div) * (2 if world > 1 else 1)      # the same ~70 M-ray sample at 3840x2160
         sw, sh_ = max(8, W // div), max(8, H // div)
         threads = min(16, os.cpu_count() or 1)
         sp = abi.render_params(sw, sh_, sh_rays=args.sh_rays, rec_max=args.rec_max, jitter=jitter, seed=1000)
@@ -261,6 +269,7 @@ def main():
         print(json.dumps(line), flush=True)
     ctx.close()
     if world > 1:
+        dist.barrier()                      # rank 0 was busy with the CPU sample: leave together
         dist.destroy_process_group()
 
 

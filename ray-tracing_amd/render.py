@@ -102,6 +102,12 @@ def gather_packed(local, rank, world, dst=0, group=None):
     import torch.distributed as dist
     if world == 1:
         return local
+    if local.is_cuda and dist.get_backend(group) != "nccl":
+        # a backend without device collectives (gloo rehearsals): the same exchange, staged through host memory
+        host = local.cpu()
+        got = torch.empty(world * host.numel(), dtype=host.dtype) if rank == dst else None
+        dist.gather(host, list(got.chunk(world)) if rank == dst else None, dst=dst, group=group)
+        return got.to(local.device) if rank == dst else None
     out = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device) if rank == dst else None
     dist.gather(local, list(out.chunk(world)) if rank == dst else None, dst=dst, group=group)
     return out
