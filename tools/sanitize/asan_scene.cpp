@@ -3,6 +3,7 @@
 // Every parse must either succeed or report an error; AddressSanitizer / UBSan watch the rest.
 //   g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -o /tmp/asan_scene tools/sanitize/asan_scene.cpp -lpthread
 //   /tmp/asan_scene tests/golden/scenes/*.txt
+// (and once more with -fsanitize=thread instead: the piece-wise parse on up to 8 threads)
 // The GPU tree build behind rt_scene_build_tree is not part of this run: its entry points are answered with RT_ERR_NO_DEVICE.
 #include "../../ray-tracing_amd/csrc/rt_scene.cpp"
 
