@@ -321,12 +321,7 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
                 const float d0 = sph ? c0 : lf.lx - Pf0, d1 = sph ? c1 : lf.ly - Pf1, d2 = sph ? c2 : lf.lz - Pf2;
                 const bool touch = !(c0 - rr > bhi0) && !(d0 + rr < blo0) && !(c1 - rr > bhi1) && !(d1 + rr < blo1) &&
                                    !(c2 - rr > bhi2) && !(d2 + rr < blo2);
-#ifdef RT_DEBUG_BEAM
-                const bool touch_dbg = touch || (dbg & 0x20000);
-#else
-                const bool touch_dbg = touch;
-#endif
-                if (touch_dbg) {
+                if (touch) {
                     bool in_cone = true;
                     if (cone_ok) {
                         // sphere (a box: its bounding sphere) against the cone: distance to the axis <= r (1 + tan) +
@@ -356,9 +351,6 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
                             }
                         }
                     }
-#ifdef RT_DEBUG_BEAM
-                    if (dbg & 0x8000) in_cone = true;
-#endif
                     if (in_cone) {
                         const uint32_t prim = lf.pk >> 2;
                         bool seen = false;               // a primitive is listed in every leaf it reaches into
@@ -415,9 +407,6 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
                     const float cu = fabsf(fmaf(c0, Q.u0, fmaf(c1, Q.u1, c2 * Q.u2))), cr = fabsf(fmaf(c0, Q.r0, fmaf(c1, Q.r1, c2 * Q.r2)));
                     const float ex = fmaxf(cu - tm - 2e-6f * cn, 0.0f), ey = fmaxf(cr - tm - 2e-6f * cn, 0.0f);
                     const float rl = fmaf(lfr, fmaf(0.5f * kt, kt, 1.001f), E);
-#ifdef RT_DEBUG_BEAM
-                    if (!(dbg & 0x4000))
-#endif
                     if (fmaf(ex, ex, ey * ey) > rl * rl) continue;
                 }
                 const float cf = (float)cd, rr = lfr, dp = __builtin_amdgcn_sqrtf(dp2);
@@ -460,9 +449,6 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
                     const float cu = fabsf(fmaf(m0_, Q.u0, fmaf(m1_, Q.u1, m2_ * Q.u2))), cr = fabsf(fmaf(m0_, Q.r0, fmaf(m1_, Q.r1, m2_ * Q.r2)));
                     const float ex = fmaxf(cu - tm - 2e-6f * cnb, 0.0f), ey = fmaxf(cr - tm - 2e-6f * cnb, 0.0f);
                     const float rl = fmaf(rb, fmaf(0.5f * kt, kt, 1.001f), E);
-#ifdef RT_DEBUG_BEAM
-                    if (!(dbg & 0x4000))
-#endif
                     if (fmaf(ex, ex, ey * ey) > rl * rl) continue;
                 }
                 const float smax = ax_len + __builtin_amdgcn_sqrtf(hh2) * 1.000001f;            // >= |sample|
