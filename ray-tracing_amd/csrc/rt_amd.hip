@@ -99,6 +99,7 @@ struct LevelParams {
     uint32_t spb, magic_s2, magic_s;     // magic_x = ceil(2^32 / x): n / x == __umulhi(n, magic_x) for n < 2^16
     int32_t beam;                        // this frame's soft shadows go through the beam path
     int32_t prio;                        // overlapped frame, deeper levels: raise the waves' issue priority
+    int32_t unit_thr;                    // level 0 holds camera rays of the fused pass: throughput 1, not stored (gen_ray<false>)
     int32_t beam_early;                  // beam traversal near side first with the umbra test inside it (scenes with long beams)
     uint32_t walk_min;                   // rays of overflowing pairs: k_shadow_walk takes them when a level has at least this
                                          // many, else k_shadow_queue expands them (same verdicts either way)
@@ -210,7 +211,10 @@ __device__ __forceinline__ Hit nearest_hit(const DScene &S, const FastScene &F, 
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-// camera ray of queue item k (ray_functions.py:31-41), written to the queue; false for a padding lane
+// camera ray of queue item k (ray_functions.py:31-41), written to the queue; false for a padding lane.
+// FULL = false (the fused camera-ray pass): origin and throughput stay unwritten - nobody traces the ray again, and
+// k_shade knows that a camera ray starts with throughput 1 (LevelParams::unit_thr): 48 of 190 bytes per pixel less.
+template <bool FULL>
 __device__ __forceinline__ bool gen_ray(const GenParams &g, const RayQ &q, uint64_t k, d3 &o, d3 &dn, uint32_t &slot) {
     uint32_t tile_local = (uint32_t)(k / (uint32_t)(g.tw * g.th));
     uint32_t lane = (uint32_t)(k % (uint32_t)(g.tw * g.th));
@@ -228,9 +232,8 @@ __device__ __forceinline__ bool gen_ray(const GenParams &g, const RayQ &q, uint6
     d3 dir = dest - pos;
     dn = dir / norm3(dir);
     o = pos;
-    q.ox[k] = pos.x; q.oy[k] = pos.y; q.oz[k] = pos.z;
+    if (FULL) { q.ox[k] = pos.x; q.oy[k] = pos.y; q.oz[k] = pos.z; q.tr[k] = 1.0; q.tg[k] = 1.0; q.tb[k] = 1.0; }
     q.dx[k] = dn.x; q.dy[k] = dn.y; q.dz[k] = dn.z;
-    q.tr[k] = 1.0; q.tg[k] = 1.0; q.tb[k] = 1.0;
     uint32_t gp = (uint32_t)y * (uint32_t)g.W + (uint32_t)x;
     slot = g.world > 1 ? (uint32_t)k : gp;
     q.slot[k] = slot;
@@ -251,7 +254,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_gen(GenParams g, RayQ q, FrameCtl 
         if (k >= g.n_slots) continue;
         d3 o, dn;
         uint32_t slot;
-        if (gen_ray(g, q, k, o, dn, slot)) valid_total++;
+        if (gen_ray<true>(g, q, k, o, dn, slot)) valid_total++;
     }
     // primary-ray count (padding lanes excluded)
     for (int off = 32; off > 0; off >>= 1) valid_total += __shfl_down(valid_total, off);
@@ -307,7 +310,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
             // every output slot is visited exactly once here: the framebuffers are initialised by plain stores
             // (fb: 0 or the background of a miss, below; fb_side: 0) instead of two memsets before the frame
             const bool in_range = active;
-            if (active) active = gen_ray(gp, q, k, o, d, slot);
+            if (active) active = gen_ray<false>(gp, q, k, o, d, slot);
             valid_total += active ? 1ull : 0ull;
             const uint32_t zs = active ? slot : ((in_range && gp.world > 1) ? (uint32_t)k : RT_INVALID_SLOT);
             if (zs != RT_INVALID_SLOT) {
@@ -1073,7 +1076,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, LevelParams lp, Ra
         if (active) {
             uint32_t r = hb.list[h];
             d3 d = mk3(q.dx[r], q.dy[r], q.dz[r]);
-            d3 thr = mk3(q.tr[r], q.tg[r], q.tb[r]);
+            d3 thr = mk3(1.0, 1.0, 1.0);
+            if (!(lp.unit_thr && lp.level == 0)) thr = mk3(q.tr[r], q.tg[r], q.tb[r]);
             d3 P = mk3(hb.px[r], hb.py[r], hb.pz[r]);
             slot = q.slot[r]; gpix = q.gpix[r]; path = q.path[r];
             int32_t id = hb.id[r], mi;
@@ -1980,6 +1984,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                           double *fb0, const GenParams *gen, double *fbm) {
     LevelParams lp{};
     lp.sh_rays = sh; lp.jitter = p->jitter; lp.seed = p->seed; lp.cap = (uint32_t)ctx->cap; lp.flags = p->flags;
+    lp.unit_thr = gen ? 1 : 0;
     {
         // k_shadow_walk pays when a level has millions of rays in overflowing pairs (1 M lattice: 17 M); with few of them
         // a second latency-bound kernel only adds its tail.  RT_AMD_WALK_MIN: 1 = always, -1 = never (diagnostic).
