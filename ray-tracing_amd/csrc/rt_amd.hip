@@ -335,7 +335,8 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                 if (GEN) { fb[3ull * slot] = S.bg[0]; fb[3ull * slot + 1] = S.bg[1]; fb[3ull * slot + 2] = S.bg[2]; }   // = 0 + 1 * bg
                 else fb_add(fb, slot, mk3(q.tr[k], q.tg[k], q.tb[k]) * ld3(S.bg));
             } else {
-                if (GEN) { fb[3ull * slot] = 0.0; fb[3ull * slot + 1] = 0.0; fb[3ull * slot + 2] = 0.0; }
+                // (with side buffers the frame is an overlapped one: k_shade<.. | RT_SHADE_STORE> stores this slot's value later)
+                if (GEN && !fb_side) { fb[3ull * slot] = 0.0; fb[3ull * slot + 1] = 0.0; fb[3ull * slot + 2] = 0.0; }
                 hb.px[k] = h.p.x; hb.py[k] = h.p.y; hb.pz[k] = h.p.z;
                 hb.id[k] = h.id;
                 has_hit = true;
