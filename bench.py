@@ -224,12 +224,21 @@ def main():
         if args.workload == "synth10k" and world == 1 and (W, H) == (1920, 1080) and os.path.exists(tfile):
             with open(tfile) as f:
                 traffic = json.load(f)["soft_shadow_family"]["hbm_bytes_per_frame_upper"]
+        # hardware counters of the same workload (committed rocprofv3 --pmc run): the share of VALU issue slots actually used
+        valu_share = None
+        vfile = os.path.join(ROOT, "profiles", "r01_p_valu_share.json")
+        if args.workload == "synth10k" and os.path.exists(vfile):
+            with open(vfile) as f:
+                vs = json.load(f)["kernels"]
+            valu_share = {"k_beam_setup": vs["k_beam_setup<false,false>"]["valu"], "k_shadow_beam": vs["k_shadow_beam"]["valu"],
+                          "k_intersect_camera_pass": vs["k_intersect<true,true>"]["valu"], "source": "profiles/r01_p_valu_share.json"}
         roofline = {
             "bound": "valu", "kernel": "soft shadows: k_beam_setup + k_shadow_beam + k_shadow_queue", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": traffic,
             "traffic_unit": "HBM bytes per frame of the soft-shadow kernels (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_q_traffic.json)",
             "achieved_is": "algorithmic flops of the reference's per-ray traversals / measured kernel time (DESIGN.md section 5)",
             "launches": prof["launches_per_family"], "kernel_ms_per_frame": round(ms_shadow, 3),
+            "valu_issue_share_measured": valu_share,
             "algorithmic_flops_per_shadow_ray": round(flops_per_shadow_ray, 1),
             "frame": {"algorithmic_flops_per_ray": round(flops_per_ray, 1),
                       "achieved_tflops": round(frame_flops / (prof["ms_total"] * 1e-3) / 1e12, 3),
