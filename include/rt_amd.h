@@ -201,6 +201,26 @@ int rt_render_device(rt_ctx *ctx, const rt_render_params *p, float *d_rgb_out, u
 int rt_sync_stats(rt_ctx *ctx, rt_stats *stats);
 
 /*
+ * rt_render_device for callers that cannot allocate.  No counterpart in the reference: it exists for code under HIP graph
+ * capture, tight serving loops and harnesses that forbid hipMalloc.  Same arguments, same image (the levels run in sequence
+ * on one buffer set; frames are bit-identical to rt_render_device's), but every buffer the frame's kernels need beyond the
+ * caller's outputs - ray queues, hit records, pair records, lit counters, framebuffers, the counter block - is carved out of
+ * one static device array inside the library (rt_noalloc_scratch_bytes() = 64 MiB per GPU, held until the process ends)
+ * instead of hipMalloc'ed memory.  The call issues no hipMalloc / hipFree / event or stream creation.
+ *   limit: the carve for (pixel slots, shadow-casting lights) must fit the array - about 4.4 KB per pixel slot with 5 such
+ *     lights (~15 000 slots, e.g. 128 x 96), 1.4 KB with one (~47 000 slots); larger frames -> RT_ERR_UNSUPPORTED with a
+ *     message naming the frame.  RT_FLAG_PROFILE -> RT_ERR_UNSUPPORTED.
+ *   queues hold 2 x the pixel slots and cannot grow: RT_ERR_QUEUE_OVERFLOW from rt_sync_stats is final for that frame.
+ *   every call on a GPU uses that GPU's one array (whatever the context): calls that overlap on one GPU - two streams, two
+ *     contexts, two threads - race; run them back to back on one stream or synchronise between them.
+ */
+int rt_render_device_noalloc(rt_ctx *ctx, const rt_render_params *p, float *d_rgb_out, uint8_t *d_rgb8_out,
+                             int32_t *d_ids_out, void *stream);
+int64_t rt_noalloc_scratch_bytes(void);
+/* Diagnostic: number of allocating HIP calls (hipMalloc, hipHostMalloc, event creation) this library has issued in the process. */
+int64_t rt_debug_alloc_calls(void);
+
+/*
  * Replaces ray_tracing(rays_sources, rays_directions, ...) (ray_tracer.py:36-133)
  * for an arbitrary ray batch: rgb_out[n*3] float64, unclipped.  Ray i plays the
  * role of pixel i for the jitter hash.

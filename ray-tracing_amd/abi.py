@@ -11,6 +11,7 @@ RT_FLAG_NO_BEAM = 4
 RT_FLAG_NO_OVERLAP = 8
 
 RT_OK = 0
+RT_ERR_INVALID_ARG, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_OOM, RT_ERR_QUEUE_OVERFLOW, RT_ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
 STATUS_NAMES = {0: "RT_OK", -1: "RT_ERR_INVALID_ARG", -2: "RT_ERR_NO_DEVICE", -3: "RT_ERR_HIP", -4: "RT_ERR_OOM",
                 -5: "RT_ERR_QUEUE_OVERFLOW", -6: "RT_ERR_UNSUPPORTED"}
 

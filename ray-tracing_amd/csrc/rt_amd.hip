@@ -36,6 +36,7 @@
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <mutex>
 
 #include "../../include/rt_amd.h"
 #include "rt_device.hpp"
@@ -1284,6 +1285,18 @@ __global__ void __launch_bounds__(RT_BLOCK) k_visibility(DScene S, FastScene F, 
         lit[k] = ray_reaches<FAST>(S, F, stk, ld3(o + 3 * k), ld3(d + 3 * k), ld3(tg + 3 * k)) ? 1 : 0;
 }
 
+// append counters of one buffer set: [0] queue entries, [1] listed pairs, [2] overflowing pairs = 0, [3] = queue capacity
+__global__ void k_init_beam_counters(uint32_t *queue_n, uint32_t queue_cap) {
+    if (threadIdx.x < 4) queue_n[threadIdx.x] = threadIdx.x == 3 ? queue_cap : 0u;
+}
+
+// rec_max < 0 (ray_tracer.py:62-63): every slot is background
+__global__ void __launch_bounds__(RT_BLOCK) k_fill_background(double *fb, uint64_t n_slots, double r, double g, double b) {
+    for (uint64_t k = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x; k < n_slots; k += (uint64_t)gridDim.x * RT_BLOCK) {
+        fb[3 * k] = r; fb[3 * k + 1] = g; fb[3 * k + 2] = b;
+    }
+}
+
 __global__ void k_deinterleave_u8(const uint8_t *packed, int64_t stride, uint8_t *image, int W, int H, int tw, int th,
                                   int tiles_x, int n_tiles, int world, int tiles_per_rank) {
     uint64_t total = (uint64_t)world * tiles_per_rank * tw * th;
@@ -1345,7 +1358,25 @@ __global__ void k_unit_slab(const double *lo, const double *hi, int outside_only
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_create_error;
 
-struct rt_ctx {
+// Everything a frame's kernels write apart from the caller's outputs: ray queues, hit records, per-pair soft-shadow state,
+// the three framebuffers and the counter block.  The allocating entry points carve it out of hipMalloc'ed buffers
+// (ensure_frame); rt_render_device_noalloc carves it out of the library's static device array (see `scratch` below) and
+// swaps it in for the duration of the enqueue.  Trivially copyable on purpose.
+struct FrameState {
+    uint64_t cap = 0;       // ray-queue capacity
+    uint64_t fb_slots = 0;
+    uint32_t beam_queue_cap = 0;
+    RayQ q[4]{};            // level 0 -> q[0]; level k >= 1 -> q[1 + (k - 1) % 2] (% 3 when the deeper levels are pipelined)
+    HitBuf hb{}, hb1{}, hb2{};   // level 0 / deeper levels, odd / deeper levels, even (so are seg*, beam*)
+    SegBuf seg{}, seg1{}, seg2{};
+    BeamBuf beam{}, beam1{}, beam2{};
+    double *fb = nullptr, *fb0 = nullptr, *fbm = nullptr;   // see k_resolve
+    bool two_sets = false;                  // hb1 / seg1 / beam1 are separate allocations
+    bool three_sets = false;                // hb2 / seg2 / beam2 are separate allocations: levels 1.. can be pipelined
+    FrameCtl *ctl = nullptr;
+};
+
+struct rt_ctx : FrameState {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string error;
@@ -1353,38 +1384,28 @@ struct rt_ctx {
     DScene S{};
     FastScene F{};
     size_t lds_bytes = 0;   // per-lane traversal stacks: F.depth * RT_BLOCK * 8
-    SegBuf seg{};
-    BeamBuf beam{};
-    uint32_t beam_queue_cap = 0;
     rt_scene_desc host{};   // scalar fields only (camera, settings)
-    // frame buffers
-    uint64_t cap = 0;       // ray-queue capacity
-    uint64_t fb_slots = 0;
     uint64_t fb_slots_frame = 0;   // primary slots of the frame being enqueued
     double growth = 2.0;    // queue capacity = growth * primary slots
     double qgrowth = 1.0;   // float64 shadow-ray queue = qgrowth * queue capacity (grows by itself: large s, many undecided rays)
     std::vector<void *> frame_allocs;
-    RayQ q[4]{};            // level 0 -> q[0]; level k >= 1 -> q[1 + (k - 1) % 2] (% 3 when the deeper levels are pipelined)
-    HitBuf hb{}, hb1{}, hb2{};   // level 0 / deeper levels, odd / deeper levels, even (so are seg*, beam*)
-    SegBuf seg1{}, seg2{};
-    BeamBuf beam1{}, beam2{};
-    double *fb = nullptr, *fb0 = nullptr, *fbm = nullptr;   // see k_resolve
-    bool three_sets = false;                // hb2 / seg2 / beam2 are separate allocations: levels 1.. can be pipelined
+    uint64_t frame_bytes = 0;               // device bytes of the frame state (ensure_frame)
+    int env_sets = 0;                       // RT_AMD_SETS / RT_AMD_ONE_SET, read once in rt_create (0 = no limit)
+    FrameCtl *ctl_own = nullptr;            // the context's own counter block (FrameState::ctl points here outside a no-alloc frame)
     hipStream_t stream3 = nullptr;          // soft shadows + Phong of levels 1.. in a pipelined frame
     std::vector<hipEvent_t> ev_hit, ev_lit; // per level: nearest hits known / shading added
     double *acc = nullptr;                  // rt_render_mean: sum of the clipped frames
     uint64_t acc_slots = 0;
-    bool two_sets = false;                  // hb1 / seg1 / beam1 are separate allocations
     hipStream_t stream2 = nullptr;          // the deeper levels of an overlapped frame
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int nb_intersect = 1, nb_beam_setup = 1, nb_beam = 1, nb_queue = 1, nb_shade = 1, nb_setup = 1, nb_shadow = 1, nb_walk = 1;   // workgroups per CU
     int g_walk = 2048;
-    FrameCtl *ctl = nullptr;
     FrameCtl *h_ctl = nullptr;   // pinned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> prof_ev;     // RT_FLAG_PROFILE: [gen0, gen1, (i0,i1,s0,s1,h0,h1) per level ..., res0, res1]
     int prof_levels = -1;                // levels bracketed in the last frame, -1 = not profiled
     bool frame_pending = false;
+    bool last_noalloc = false;           // the last frame came through rt_render_device_noalloc: its queues cannot grow
     rt_render_params last{};
     int32_t last_sh = 0, last_rec = 0;
     uint64_t last_slots = 0;
@@ -1417,6 +1438,41 @@ static int fail(rt_ctx *ctx, int code, const std::string &msg) {
         }                                                                                                    \
     } while (0)
 
+// every allocating HIP call of this library goes through these (rt_debug_alloc_calls counts them: the no-alloc entry point's
+// test asserts that a call leaves the count unchanged)
+static std::atomic<long long> g_alloc_calls(0);
+template <typename T>
+static hipError_t rt_malloc(T **p, size_t bytes) { g_alloc_calls++; return hipMalloc((void **)p, bytes); }
+static hipError_t rt_host_malloc(void **p, size_t bytes) { g_alloc_calls++; return hipHostMalloc(p, bytes, hipHostMallocDefault); }
+static hipError_t rt_event_create(hipEvent_t *e, bool timing) { g_alloc_calls++; return timing ? hipEventCreate(e) : hipEventCreateWithFlags(e, hipEventDisableTiming); }
+
+// The no-alloc entry point's memory (rt_render_device_noalloc): every buffer ensure_frame would hipMalloc for a small frame is
+// carved out of this array instead.  In host code the NAME `scratch` is only a stand-in for the symbol: the device address comes
+// from hipGetSymbolAddress, once per device, and only that pointer is ever handed to kernels, memsets or copies.
+// Each GPU the library runs on holds its own copy (RT_SCRATCH_BYTES of HBM) until the process ends.
+#define RT_SCRATCH_BYTES (64ull << 20)
+#define RT_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[RT_SCRATCH_BYTES];
+static unsigned char *g_scratch_ptr[RT_MAX_DEVICES];      // per device ordinal; nullptr = not looked up yet
+static std::mutex g_scratch_mutex;
+
+// device address of `scratch` on `device` (which must be the current device)
+static int scratch_address(rt_ctx *ctx, int device, unsigned char **out) {
+    if (device < 0 || device >= RT_MAX_DEVICES) { if (out) *out = nullptr; return RT_OK; }     // no no-alloc frames on such a device
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        HIP_TRY(ctx, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p || ((uintptr_t)p & 255u)) return fail(ctx, RT_ERR_HIP, "hipGetSymbolAddress(scratch) gave a null or misaligned address");
+        g_scratch_ptr[device] = (unsigned char *)p;
+    }
+    if (out) *out = g_scratch_ptr[device];
+    return RT_OK;
+}
+
+extern "C" int64_t rt_debug_alloc_calls(void) { return (int64_t)g_alloc_calls.load(); }
+extern "C" int64_t rt_noalloc_scratch_bytes(void) { return (int64_t)RT_SCRATCH_BYTES; }
+
 // host loops of rt_create over millions of independent records: cut into contiguous pieces, one thread each
 // (nothing below 64 k records; at most 16 threads, the GPU box's CPU share)
 template <typename Fn>
@@ -1438,7 +1494,7 @@ template <typename T>
 static int upload(rt_ctx *ctx, std::vector<void *> &owner, const std::vector<T> &h, const T **out) {
     void *p = nullptr;
     size_t bytes = (h.size() ? h.size() : 1) * sizeof(T);
-    HIP_TRY(ctx, hipMalloc(&p, bytes));
+    HIP_TRY(ctx, rt_malloc(&p, bytes));
     owner.push_back(p);
     if (!h.empty()) HIP_TRY(ctx, hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     *out = (const T *)p;
@@ -1521,15 +1577,17 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
 #define HIP_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ctx->error = std::string(#expr) + ": " + hipGetErrorString(e_); return bail(e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP); } } while (0)
     HIP_C(hipSetDevice(device));
     HIP_C(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    HIP_C(hipEventCreate(&ctx->ev0));
-    HIP_C(hipEventCreate(&ctx->ev1));
+    HIP_C(rt_event_create(&ctx->ev0, true));
+    HIP_C(rt_event_create(&ctx->ev1, true));
     // (a high-priority stream here hung the GPU under the persistent level-0 kernels; wave priority is set in the kernels instead)
     HIP_C(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
     HIP_C(hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
-    HIP_C(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    HIP_C(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    HIP_C(hipMalloc((void **)&ctx->ctl, sizeof(FrameCtl)));
-    HIP_C(hipHostMalloc((void **)&ctx->h_ctl, sizeof(FrameCtl), hipHostMallocDefault));
+    HIP_C(rt_event_create(&ctx->ev_fork, false));
+    HIP_C(rt_event_create(&ctx->ev_join, false));
+    HIP_C(rt_malloc(&ctx->ctl_own, sizeof(FrameCtl)));
+    ctx->ctl = ctx->ctl_own;
+    if (int rc = scratch_address(ctx, device, nullptr)) return bail(rc);      // the no-alloc entry point's buffer on this device, looked up once
+    HIP_C(rt_host_malloc((void **)&ctx->h_ctl, sizeof(FrameCtl)));
     hipDeviceProp_t prop;
     HIP_C(hipGetDeviceProperties(&prop, device));
     ctx->n_cu = prop.multiProcessorCount;
@@ -1786,6 +1844,8 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
     }
     for (int k = 0; k < 3; ++k) ctx->S.bg[k] = s->background[k];
     tick("surface / material / light tables");
+    if (const char *lim = getenv("RT_AMD_SETS")) ctx->env_sets = atoi(lim);      // 1, 2 or 3 buffer sets (diagnostic)
+    if (getenv("RT_AMD_ONE_SET")) ctx->env_sets = 1;
     ctx->host = *s;   // pointers inside are NOT used after this call; scalars (camera, settings) are
 #undef TRY_C
 #undef HIP_C
@@ -1796,11 +1856,9 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
 static void free_frame(rt_ctx *ctx) {
     for (void *p : ctx->frame_allocs) (void)hipFree(p);
     ctx->frame_allocs.clear();
-    ctx->cap = 0;
-    ctx->fb_slots = 0;
-    ctx->fb = nullptr;
-    ctx->fbm = nullptr;
-    ctx->fb0 = nullptr;
+    FrameState empty;
+    empty.ctl = ctx->ctl_own;
+    static_cast<FrameState &>(*ctx) = empty;
 }
 
 extern "C" int rt_destroy(rt_ctx *ctx) {
@@ -1809,7 +1867,7 @@ extern "C" int rt_destroy(rt_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_frame(ctx);
     for (void *p : ctx->scene_allocs) (void)hipFree(p);
-    if (ctx->ctl) (void)hipFree(ctx->ctl);
+    if (ctx->ctl_own) (void)hipFree(ctx->ctl_own);
     if (ctx->acc) (void)hipFree(ctx->acc);
     if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -1826,12 +1884,86 @@ extern "C" int rt_destroy(rt_ctx *ctx) {
     return RT_OK;
 }
 
-template <typename T>
-static int dalloc(rt_ctx *ctx, T **p, uint64_t n) {
-    void *v = nullptr;
-    HIP_TRY(ctx, hipMalloc(&v, (n ? n : 1) * sizeof(T)));
-    ctx->frame_allocs.push_back(v);
-    *p = (T *)v;
+// ------------------------------------------------------------------------------------------------
+// frame state: one carving routine, two sources of memory
+// ------------------------------------------------------------------------------------------------
+// Memory source of carve_frame: one hipMalloc per buffer (owned by the context), or a bump pointer inside `scratch`.
+struct Carver {
+    rt_ctx *ctx;
+    unsigned char *base = nullptr;   // bump mode: start of the region (device address), else nullptr
+    uint64_t used = 0, limit = 0;
+    template <typename T>
+    int get(T **p, uint64_t n) {
+        const uint64_t bytes = ((n ? n : 1) * sizeof(T) + 255ull) & ~255ull;
+        if (base) {
+            if (used + bytes > limit) return fail(ctx, RT_ERR_UNSUPPORTED, "frame does not fit the static scratch buffer of the no-alloc entry point");
+            *p = (T *)(base + used);
+            used += bytes;
+            return RT_OK;
+        }
+        void *v = nullptr;
+        HIP_TRY(ctx, rt_malloc(&v, bytes));
+        ctx->frame_allocs.push_back(v);
+        *p = (T *)v;
+        used += bytes;
+        return RT_OK;
+    }
+};
+
+// Carve the state of a frame of `slots` primary slots with queue capacity `cap` into fs.  sets = 1..3 buffer sets (level 0 /
+// deeper levels odd / even); queues = 3 (levels in sequence) or 4 (pipelined deeper levels).  Nothing is initialised here.
+static int carve_frame(rt_ctx *ctx, Carver &mem, FrameState &fs, uint64_t slots, uint64_t cap, uint32_t queue_cap, int sets, int queues) {
+#define TRY_A(expr) do { int rc_ = (expr); if (rc_ != RT_OK) return rc_; } while (0)
+    for (int i = 0; i < queues; ++i) {
+        RayQ &q = fs.q[i];
+        TRY_A(mem.get(&q.ox, cap)); TRY_A(mem.get(&q.oy, cap)); TRY_A(mem.get(&q.oz, cap));
+        TRY_A(mem.get(&q.dx, cap)); TRY_A(mem.get(&q.dy, cap)); TRY_A(mem.get(&q.dz, cap));
+        TRY_A(mem.get(&q.tr, cap)); TRY_A(mem.get(&q.tg, cap)); TRY_A(mem.get(&q.tb, cap));
+        TRY_A(mem.get(&q.slot, cap)); TRY_A(mem.get(&q.gpix, cap)); TRY_A(mem.get(&q.path, cap));
+    }
+    for (int i = queues; i < 4; ++i) fs.q[i] = fs.q[queues - 1];
+    const uint64_t nlit = cap * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1);
+    fs.beam_queue_cap = queue_cap;
+    for (int set = 0; set < sets; ++set) {
+        HitBuf &hb = set == 0 ? fs.hb : (set == 1 ? fs.hb1 : fs.hb2);
+        TRY_A(mem.get(&hb.px, cap)); TRY_A(mem.get(&hb.py, cap)); TRY_A(mem.get(&hb.pz, cap));
+        TRY_A(mem.get(&hb.id, cap)); TRY_A(mem.get(&hb.list, cap));
+        TRY_A(mem.get(&hb.lit, nlit));
+        SegBuf &sg = set == 0 ? fs.seg : (set == 1 ? fs.seg1 : fs.seg2);
+        TRY_A(mem.get(&sg.ux, nlit)); TRY_A(mem.get(&sg.uy, nlit)); TRY_A(mem.get(&sg.uz, nlit));
+        TRY_A(mem.get(&sg.rx, nlit)); TRY_A(mem.get(&sg.ry, nlit)); TRY_A(mem.get(&sg.rz, nlit));
+        TRY_A(mem.get(&sg.cx, nlit)); TRY_A(mem.get(&sg.cy, nlit)); TRY_A(mem.get(&sg.cz, nlit));
+        BeamBuf &bb = set == 0 ? fs.beam : (set == 1 ? fs.beam1 : fs.beam2);
+        TRY_A(mem.get(&bb.rec, (nlit + RT_BLOCK) * RT_PAIR_UNITS));   // + one chunk of slack: staging reads whole chunks
+        TRY_A(mem.get(&bb.queue, (uint64_t)queue_cap)); TRY_A(mem.get(&bb.queue_n, 4));
+        TRY_A(mem.get(&bb.litbits, (nlit + 1) * (RT_BLOCK / 64)));      // worst case one pair per chunk (s*s > RT_BLOCK / 2)
+        TRY_A(mem.get(&bb.list, nlit)); TRY_A(mem.get(&bb.pair_slot, nlit)); TRY_A(mem.get(&bb.ovlist, nlit));
+    }
+    if (sets < 2) { fs.hb1 = fs.hb; fs.seg1 = fs.seg; fs.beam1 = fs.beam; }
+    if (sets < 3) { fs.hb2 = fs.hb1; fs.seg2 = fs.seg1; fs.beam2 = fs.beam1; }
+    fs.two_sets = sets >= 2;
+    fs.three_sets = sets >= 3;
+    TRY_A(mem.get(&fs.fb0, slots * 3));
+    TRY_A(mem.get(&fs.fb, slots * 3));
+    TRY_A(mem.get(&fs.fbm, slots * 3));
+#undef TRY_A
+    fs.cap = cap;
+    fs.fb_slots = slots;
+    return RT_OK;
+}
+
+// what must hold before the first frame on freshly carved (or reused static) buffers: lit counters zero - k_shade resets them
+// only as it consumes them, a frame voided by a queue overflow leaves counts behind -, append counters zero, queue capacity set
+static int init_frame_counters(rt_ctx *ctx, FrameState &fs, hipStream_t st) {
+    const uint64_t nlit = fs.cap * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1);
+    const int sets = fs.three_sets ? 3 : (fs.two_sets ? 2 : 1);
+    for (int set = 0; set < sets; ++set) {
+        HitBuf &hb = set == 0 ? fs.hb : (set == 1 ? fs.hb1 : fs.hb2);
+        BeamBuf &bb = set == 0 ? fs.beam : (set == 1 ? fs.beam1 : fs.beam2);
+        HIP_TRY(ctx, hipMemsetAsync(hb.lit, 0, nlit * sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_init_beam_counters, dim3(1), dim3(64), 0, st, bb.queue_n, fs.beam_queue_cap);
+    }
+    HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
 }
 
@@ -1844,57 +1976,30 @@ static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
     if (ctx->cap >= want_cap && ctx->fb_slots >= slots && ctx->beam_queue_cap >= want_q) return RT_OK;
     HIP_TRY(ctx, hipDeviceSynchronize());   // rare: buffers of an in-flight frame are about to be replaced
     free_frame(ctx);
-    uint64_t cap = want_cap;
-#define TRY_A(expr) do { int rc_ = (expr); if (rc_ != RT_OK) { free_frame(ctx); return rc_; } } while (0)
-    for (int i = 0; i < 4; ++i) {
-        RayQ &q = ctx->q[i];
-        TRY_A(dalloc(ctx, &q.ox, cap)); TRY_A(dalloc(ctx, &q.oy, cap)); TRY_A(dalloc(ctx, &q.oz, cap));
-        TRY_A(dalloc(ctx, &q.dx, cap)); TRY_A(dalloc(ctx, &q.dy, cap)); TRY_A(dalloc(ctx, &q.dz, cap));
-        TRY_A(dalloc(ctx, &q.tr, cap)); TRY_A(dalloc(ctx, &q.tg, cap)); TRY_A(dalloc(ctx, &q.tb, cap));
-        TRY_A(dalloc(ctx, &q.slot, cap)); TRY_A(dalloc(ctx, &q.gpix, cap)); TRY_A(dalloc(ctx, &q.path, cap));
-    }
-    uint64_t nlit = cap * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1);
-    ctx->beam_queue_cap = want_q;
-    ctx->two_sets = true;
-    ctx->three_sets = true;
-    for (int set = 0; set < 3; ++set) {          // level 0 / deeper levels (odd, even): the parts of an overlapped frame
-        if (set >= 1) {
-            // the second and third set are speed-ups only: without the memory for them levels share a set and run in sequence
-            size_t free_b = 0, total_b = 0;
-            const uint64_t need_b = cap * 40 + nlit * (4 + 72 + 16 * RT_PAIR_UNITS + 8 * (RT_BLOCK / 64) + 12) + (uint64_t)ctx->beam_queue_cap * 8;
-            const char *lim = getenv("RT_AMD_SETS");      // 1, 2 or 3 (diagnostic)
-            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (uint64_t)free_b < need_b + need_b / 8 + slots * 48 || getenv("RT_AMD_ONE_SET") ||
-                (lim && atoi(lim) <= set)) {
-                if (set == 1) { ctx->hb1 = ctx->hb; ctx->seg1 = ctx->seg; ctx->beam1 = ctx->beam; ctx->two_sets = false; }
-                ctx->hb2 = ctx->hb1; ctx->seg2 = ctx->seg1; ctx->beam2 = ctx->beam1;
-                ctx->three_sets = false;
-                break;
-            }
+    const uint64_t cap = want_cap;
+    const uint64_t nlit = cap * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1);
+    // the second and third buffer set are speed-ups only: without the memory for them levels share a set and run in sequence
+    int sets = 3;
+    {
+        size_t free_b = 0, total_b = 0;
+        const uint64_t queues_b = 4 * cap * 84, fb_b = slots * 72;
+        const uint64_t set_b = cap * 40 + nlit * (4 + 72 + 16 * RT_PAIR_UNITS + 8 * (RT_BLOCK / 64) + 12) + (uint64_t)want_q * 8;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) sets = 1;
+        else {
+            const uint64_t avail = (uint64_t)free_b > queues_b + fb_b ? (uint64_t)free_b - queues_b - fb_b : 0;
+            while (sets > 1 && avail < (uint64_t)sets * (set_b + set_b / 8)) --sets;
         }
-        HitBuf &hb = set == 0 ? ctx->hb : (set == 1 ? ctx->hb1 : ctx->hb2);
-        TRY_A(dalloc(ctx, &hb.px, cap)); TRY_A(dalloc(ctx, &hb.py, cap)); TRY_A(dalloc(ctx, &hb.pz, cap));
-        TRY_A(dalloc(ctx, &hb.id, cap)); TRY_A(dalloc(ctx, &hb.list, cap));
-        TRY_A(dalloc(ctx, &hb.lit, nlit));
-        HIP_TRY(ctx, hipMemsetAsync(hb.lit, 0, nlit * sizeof(uint32_t), ctx->stream));
-        SegBuf &sg = set == 0 ? ctx->seg : (set == 1 ? ctx->seg1 : ctx->seg2);
-        TRY_A(dalloc(ctx, &sg.ux, nlit)); TRY_A(dalloc(ctx, &sg.uy, nlit)); TRY_A(dalloc(ctx, &sg.uz, nlit));
-        TRY_A(dalloc(ctx, &sg.rx, nlit)); TRY_A(dalloc(ctx, &sg.ry, nlit)); TRY_A(dalloc(ctx, &sg.rz, nlit));
-        TRY_A(dalloc(ctx, &sg.cx, nlit)); TRY_A(dalloc(ctx, &sg.cy, nlit)); TRY_A(dalloc(ctx, &sg.cz, nlit));
-        BeamBuf &bb = set == 0 ? ctx->beam : (set == 1 ? ctx->beam1 : ctx->beam2);
-        TRY_A(dalloc(ctx, &bb.rec, (nlit + RT_BLOCK) * RT_PAIR_UNITS));   // + one chunk of slack: staging reads whole chunks
-        TRY_A(dalloc(ctx, &bb.queue, (uint64_t)ctx->beam_queue_cap)); TRY_A(dalloc(ctx, &bb.queue_n, 4));
-        TRY_A(dalloc(ctx, &bb.litbits, (nlit + 1) * (RT_BLOCK / 64)));      // worst case one pair per chunk (s*s > RT_BLOCK / 2)
-        TRY_A(dalloc(ctx, &bb.list, nlit)); TRY_A(dalloc(ctx, &bb.pair_slot, nlit)); TRY_A(dalloc(ctx, &bb.ovlist, nlit));
-        uint32_t init[4] = {0u, 0u, 0u, ctx->beam_queue_cap};
-        HIP_TRY(ctx, hipMemcpy(bb.queue_n, init, sizeof(init), hipMemcpyHostToDevice));
+        if (ctx->env_sets > 0 && ctx->env_sets < sets) sets = ctx->env_sets;      // RT_AMD_SETS = 1, 2 or 3 / RT_AMD_ONE_SET (diagnostic)
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    TRY_A(dalloc(ctx, &ctx->fb0, slots * 3));
-    TRY_A(dalloc(ctx, &ctx->fb, slots * 3));
-    TRY_A(dalloc(ctx, &ctx->fbm, slots * 3));
-#undef TRY_A
-    ctx->cap = cap;
-    ctx->fb_slots = slots;
+    Carver mem{ctx};
+    FrameState fs;
+    fs.ctl = ctx->ctl_own;
+    int rc = carve_frame(ctx, mem, fs, slots, cap, want_q, sets, 4);
+    if (rc == RT_OK) rc = init_frame_counters(ctx, fs, ctx->stream);
+    if (rc == RT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, RT_ERR_HIP, "hipStreamSynchronize failed after frame set-up");
+    if (rc != RT_OK) { free_frame(ctx); return rc; }
+    static_cast<FrameState &>(*ctx) = fs;
+    ctx->frame_bytes = mem.used;
     return RT_OK;
 }
 
@@ -1962,7 +2067,7 @@ static int prof_prepare(rt_ctx *ctx, int levels) {
     size_t need = 4 + 6 * (size_t)levels;
     while (ctx->prof_ev.size() < need) {
         hipEvent_t e;
-        HIP_TRY(ctx, hipEventCreate(&e));
+        HIP_TRY(ctx, rt_event_create(&e, true));
         ctx->prof_ev.push_back(e);
     }
     ctx->prof_levels = levels;
@@ -2118,9 +2223,9 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
             hipStream_t s3_ = ctx->stream3;
             while ((int)ctx->ev_hit.size() <= rec) {
                 hipEvent_t a, b;
-                HIP_TRY(ctx, hipEventCreateWithFlags(&a, hipEventDisableTiming));
+                HIP_TRY(ctx, rt_event_create(&a, false));
                 ctx->ev_hit.push_back(a);
-                HIP_TRY(ctx, hipEventCreateWithFlags(&b, hipEventDisableTiming));
+                HIP_TRY(ctx, rt_event_create(&b, false));
                 ctx->ev_lit.push_back(b);
             }
             auto pq = [&](int level) -> RayQ & { return ctx->q[1 + (level - 1) % 3]; };
@@ -2167,23 +2272,10 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
     return RT_OK;
 }
 
-extern "C" int rt_render_device(rt_ctx *ctx, const rt_render_params *p, float *d_rgb, uint8_t *d_rgb8, int32_t *d_ids,
-                                void *stream) {
-    if (!ctx) return RT_ERR_INVALID_ARG;
-    TileGeom g;
-    std::string why;
-    if (int rc = tile_geom(p, g, why)) return fail(ctx, rc, why);
-    int32_t sh, rec;
-    if (int rc = resolve_settings(ctx, p, sh, rec)) return rc;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    uint64_t need = g.slots > g.out_slots ? g.slots : g.out_slots;
-    if (int rc = ensure_frame(ctx, need)) return rc;
-    ctx->fb_slots_frame = g.slots;
-
+// camera constants of a frame (ray_functions.py:17-25; host, once per frame)
+static GenParams gen_params(const rt_ctx *ctx, const TileGeom &g) {
     GenParams gp{};
     const rt_scene_desc &s = ctx->host;
-    // ray_functions.py:17-25 (host, once per frame)
     double w = s.cam_screen_width;
     double h = w / g.W * g.H;
     gp.hg = h / g.H;
@@ -2195,13 +2287,17 @@ extern "C" int rt_render_device(rt_ctx *ctx, const rt_render_params *p, float *d
     }
     gp.W = g.W; gp.H = g.H; gp.tiles_x = g.tiles_x; gp.n_tiles = g.n_tiles; gp.rank = g.rank; gp.world = g.world;
     gp.tw = g.tw; gp.th = g.th; gp.n_slots = (uint32_t)g.slots;
+    return gp;
+}
 
-    const bool prof = (p->flags & RT_FLAG_PROFILE) != 0 && rec >= 0;
-    ctx->prof_levels = -1;
-    if (prof) { if (int rc = prof_prepare(ctx, rec + 1)) return rc; }
+// enqueue one camera frame on st; the frame state (queues, framebuffers, counters) is whatever ctx currently holds
+static int enqueue_frame(rt_ctx *ctx, const rt_render_params *p, const TileGeom &g, int32_t sh, int32_t rec, float *d_rgb,
+                         uint8_t *d_rgb8, int32_t *d_ids, hipStream_t st, bool prof) {
+    ctx->fb_slots_frame = g.slots;
+    const GenParams gp = gen_params(ctx, g);
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
     HIP_TRY(ctx, hipMemsetAsync(ctx->ctl, 0, sizeof(FrameCtl), st));
-    if (prof || rec < 0) {      // otherwise k_intersect(0) initialises both framebuffers while it makes the camera rays
+    if (prof) {      // otherwise k_intersect(0) initialises the framebuffers while it makes the camera rays
         HIP_TRY(ctx, hipMemsetAsync(ctx->fb, 0, g.out_slots * 3 * sizeof(double), st));
         HIP_TRY(ctx, hipMemsetAsync(ctx->fb0, 0, g.out_slots * 3 * sizeof(double), st));
         HIP_TRY(ctx, hipMemsetAsync(ctx->fbm, 0, g.out_slots * 3 * sizeof(double), st));
@@ -2210,10 +2306,10 @@ extern "C" int rt_render_device(rt_ctx *ctx, const rt_render_params *p, float *d
     dim3 grid(ctx->grid), block(RT_BLOCK);
     if (rec < 0) {
         // ray_tracer.py:62-63: everything is background; expressed as a frame with no levels
-        std::vector<double> bgfill(g.out_slots * 3);
-        for (uint64_t k = 0; k < g.out_slots; ++k) for (int c = 0; c < 3; ++c) bgfill[3 * k + c] = s.background[c];
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->fb, bgfill.data(), bgfill.size() * sizeof(double), hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));
+        const rt_scene_desc &s = ctx->host;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->fb0, 0, g.out_slots * 3 * sizeof(double), st));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->fbm, 0, g.out_slots * 3 * sizeof(double), st));
+        hipLaunchKernelGGL(k_fill_background, grid, block, 0, st, ctx->fb, g.out_slots, s.background[0], s.background[1], s.background[2]);
     } else {
         // camera rays: inside k_intersect(0); as a launch of their own only when the kernel families are timed
         PROF_MARK(0);
@@ -2230,6 +2326,69 @@ extern "C" int rt_render_device(rt_ctx *ctx, const rt_render_params *p, float *d
     ctx->frame_pending = true;
     ctx->last = *p; ctx->last_sh = sh; ctx->last_rec = rec; ctx->last_slots = g.slots; ctx->last_gen = true;
     return RT_OK;
+}
+
+extern "C" int rt_render_device(rt_ctx *ctx, const rt_render_params *p, float *d_rgb, uint8_t *d_rgb8, int32_t *d_ids,
+                                void *stream) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    TileGeom g;
+    std::string why;
+    if (int rc = tile_geom(p, g, why)) return fail(ctx, rc, why);
+    int32_t sh, rec;
+    if (int rc = resolve_settings(ctx, p, sh, rec)) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    uint64_t need = g.slots > g.out_slots ? g.slots : g.out_slots;
+    if (int rc = ensure_frame(ctx, need)) return rc;
+    const bool prof = (p->flags & RT_FLAG_PROFILE) != 0 && rec >= 0;
+    ctx->prof_levels = -1;
+    if (prof) { if (int rc = prof_prepare(ctx, rec + 1)) return rc; }
+    ctx->last_noalloc = false;
+    return enqueue_frame(ctx, p, g, sh, rec, d_rgb, d_rgb8, d_ids, st, prof);
+}
+
+// rt_render_device for callers that cannot allocate (include/rt_amd.h): the frame state lives in `scratch`, carved by the same
+// routine that lays out the hipMalloc'ed buffers; levels run in sequence on ONE buffer set (the overlapped schedule needs two
+// more sets and per-level events).  No hipMalloc / hipFree / event or stream creation on this path.  Every call on a device
+// reuses that device's array from offset 0: what must start at zero (lit counters, append counters, the counter block) is
+// cleared on the stream before the frame, so a voided or larger earlier frame leaves nothing behind.
+extern "C" int rt_render_device_noalloc(rt_ctx *ctx, const rt_render_params *p, float *d_rgb, uint8_t *d_rgb8, int32_t *d_ids,
+                                        void *stream) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    TileGeom g;
+    std::string why;
+    if (int rc = tile_geom(p, g, why)) return fail(ctx, rc, why);
+    int32_t sh, rec;
+    if (int rc = resolve_settings(ctx, p, sh, rec)) return rc;
+    if (p->flags & RT_FLAG_PROFILE) return fail(ctx, RT_ERR_UNSUPPORTED, "RT_FLAG_PROFILE creates events: not available on the no-alloc entry point");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    unsigned char *base = nullptr;
+    if (int rc = scratch_address(ctx, ctx->device, &base)) return rc;
+    if (!base) return fail(ctx, RT_ERR_UNSUPPORTED, "no static scratch buffer on this device ordinal");
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    const uint64_t slots = g.slots > g.out_slots ? g.slots : g.out_slots;
+    const uint64_t cap = 2 * slots + 1024;             // the allocating path's initial growth; it cannot grow here
+    Carver mem{ctx};
+    mem.base = base;
+    mem.limit = RT_SCRATCH_BYTES;
+    FrameState fs;
+    if (int rc = mem.get(&fs.ctl, 1)) return rc;
+    if (int rc = carve_frame(ctx, mem, fs, slots, cap, (uint32_t)cap, 1, 3)) {
+        char msg[256];
+        snprintf(msg, sizeof(msg), "rt_render_device_noalloc: a frame of %llu pixel slots with %d shadow-casting lights does not fit the %llu MiB static scratch buffer",
+                 (unsigned long long)slots, ctx->S.n_shadow_lights, (unsigned long long)(RT_SCRATCH_BYTES >> 20));
+        return fail(ctx, rc, msg);
+    }
+    const FrameState saved = static_cast<FrameState &>(*ctx);
+    static_cast<FrameState &>(*ctx) = fs;
+    rt_render_params q = *p;
+    q.flags |= RT_FLAG_NO_OVERLAP;
+    int rc = init_frame_counters(ctx, fs, st);
+    ctx->prof_levels = -1;
+    if (rc == RT_OK) rc = enqueue_frame(ctx, &q, g, sh, rec, d_rgb, d_rgb8, d_ids, st, false);
+    static_cast<FrameState &>(*ctx) = saved;            // the kernels hold their pointers by value
+    ctx->last_noalloc = true;
+    return rc;
 }
 
 extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
@@ -2306,6 +2465,7 @@ extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
     }
     if (c.overflow) {
         // the next frame gets larger queues: the one that ran out
+        if (ctx->last_noalloc) return fail(ctx, RT_ERR_QUEUE_OVERFLOW, "secondary-ray queue overflow in a no-alloc frame (its queues hold 2 x the pixel slots and cannot grow); nothing valid was written");
         if (c.overflow_q && ctx->beam_queue_cap < 0x7fffffffu) ctx->qgrowth *= 8.0;
         else ctx->growth *= 2.0;
         return fail(ctx, RT_ERR_QUEUE_OVERFLOW, "secondary-ray queue overflow; queue growth factor doubled, render again");
@@ -2330,9 +2490,9 @@ extern "C" int rt_render(rt_ctx *ctx, const rt_render_params *p, float *rgb_out,
         if (d_ids) (void)hipFree(d_ids);
     };
 #define TRY_R(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
-    if (rgb_out) TRY_R(hipMalloc((void **)&d_rgb, g.out_slots * 3 * sizeof(float)));
-    if (rgb8_out || !rgb_out) TRY_R(hipMalloc((void **)&d_rgb8, g.out_slots * 3));
-    if (ids_out) TRY_R(hipMalloc((void **)&d_ids, g.out_slots * sizeof(int32_t)));
+    if (rgb_out) TRY_R(rt_malloc(&d_rgb, g.out_slots * 3 * sizeof(float)));
+    if (rgb8_out || !rgb_out) TRY_R(rt_malloc(&d_rgb8, g.out_slots * 3));
+    if (ids_out) TRY_R(rt_malloc(&d_ids, g.out_slots * sizeof(int32_t)));
     for (int attempt = 0; attempt < 10; ++attempt) {
         rc = rt_render_device(ctx, p, d_rgb, d_rgb8, d_ids, nullptr);
         if (rc != RT_OK) break;
@@ -2361,7 +2521,7 @@ extern "C" int rt_render_mean(rt_ctx *ctx, const rt_render_params *p, int32_t fr
         if (ctx->acc) (void)hipFree(ctx->acc);
         ctx->acc = nullptr;
         ctx->acc_slots = 0;
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->acc, g.out_slots * 3 * sizeof(double)));
+        HIP_TRY(ctx, rt_malloc(&ctx->acc, g.out_slots * 3 * sizeof(double)));
         ctx->acc_slots = g.out_slots;
     }
     float *d_rgb = nullptr;
@@ -2372,8 +2532,8 @@ extern "C" int rt_render_mean(rt_ctx *ctx, const rt_render_params *p, int32_t fr
         if (d_rgb8) (void)hipFree(d_rgb8);
     };
 #define TRY_M(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
-    if (rgb_out) TRY_M(hipMalloc((void **)&d_rgb, g.out_slots * 3 * sizeof(float)));
-    if (rgb8_out) TRY_M(hipMalloc((void **)&d_rgb8, g.out_slots * 3));
+    if (rgb_out) TRY_M(rt_malloc(&d_rgb, g.out_slots * 3 * sizeof(float)));
+    if (rgb8_out) TRY_M(rt_malloc(&d_rgb8, g.out_slots * 3));
     rt_stats sum;
     memset(&sum, 0, sizeof(sum));
     for (int32_t k = 0; k < frames && rc == RT_OK; ++k) {
@@ -2424,8 +2584,8 @@ extern "C" int rt_trace(rt_ctx *ctx, const rt_render_params *p, const double *or
         if (d_d) (void)hipFree(d_d);
     };
 #define TRY_T(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
-    TRY_T(hipMalloc((void **)&d_o, (size_t)n * 3 * sizeof(double)));
-    TRY_T(hipMalloc((void **)&d_d, (size_t)n * 3 * sizeof(double)));
+    TRY_T(rt_malloc(&d_o, (size_t)n * 3 * sizeof(double)));
+    TRY_T(rt_malloc(&d_d, (size_t)n * 3 * sizeof(double)));
     TRY_T(hipMemcpy(d_o, origins, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice));
     TRY_T(hipMemcpy(d_d, directions, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice));
     for (int attempt = 0; attempt < 10; ++attempt) {
@@ -2434,10 +2594,9 @@ extern "C" int rt_trace(rt_ctx *ctx, const rt_render_params *p, const double *or
         TRY_T(hipEventRecord(ctx->ev0, st));
         TRY_T(hipMemsetAsync(ctx->ctl, 0, sizeof(FrameCtl), st));
         TRY_T(hipMemsetAsync(ctx->fb, 0, (size_t)n * 3 * sizeof(double), st));
-        if (rec < 0) {
-            std::vector<double> bgfill((size_t)n * 3);
-            for (int64_t k = 0; k < n; ++k) for (int c = 0; c < 3; ++c) bgfill[3 * k + c] = ctx->host.background[c];
-            TRY_T(hipMemcpy(ctx->fb, bgfill.data(), bgfill.size() * sizeof(double), hipMemcpyHostToDevice));
+        if (rec < 0) {     // ray_tracer.py:62-63 (on the frame's stream, after the memset above)
+            hipLaunchKernelGGL(k_fill_background, dim3(ctx->grid), dim3(RT_BLOCK), 0, st, ctx->fb, (uint64_t)n, ctx->host.background[0],
+                               ctx->host.background[1], ctx->host.background[2]);
         } else {
             hipLaunchKernelGGL(k_load_rays, dim3(ctx->grid), dim3(RT_BLOCK), 0, st, d_o, d_d, (uint32_t)n, ctx->q[0], ctx->ctl);
             rt_render_params pp = *p;
@@ -2474,10 +2633,10 @@ extern "C" int rt_intersect(rt_ctx *ctx, const double *origins, const double *di
     };
 #define TRY_I(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
     size_t vb = (size_t)n * 3 * sizeof(double);
-    TRY_I(hipMalloc((void **)&d_o, vb));
-    TRY_I(hipMalloc((void **)&d_d, vb));
-    TRY_I(hipMalloc((void **)&d_p, vb));
-    TRY_I(hipMalloc((void **)&d_i, (size_t)n * sizeof(int64_t)));
+    TRY_I(rt_malloc(&d_o, vb));
+    TRY_I(rt_malloc(&d_d, vb));
+    TRY_I(rt_malloc(&d_p, vb));
+    TRY_I(rt_malloc(&d_i, (size_t)n * sizeof(int64_t)));
     TRY_I(hipMemcpy(d_o, origins, vb, hipMemcpyHostToDevice));
     TRY_I(hipMemcpy(d_d, directions, vb, hipMemcpyHostToDevice));
     if (ctx->F.ok && !getenv("RT_AMD_EXACT"))
@@ -2507,8 +2666,8 @@ extern "C" int rt_visibility(rt_ctx *ctx, const double *origins, const double *d
     };
 #define TRY_V(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
     const size_t vn = (size_t)n * 3, vb = vn * sizeof(double);
-    TRY_V(hipMalloc((void **)&d_v, 3 * vb));
-    TRY_V(hipMalloc((void **)&d_l, (size_t)n));
+    TRY_V(rt_malloc(&d_v, 3 * vb));
+    TRY_V(rt_malloc(&d_l, (size_t)n));
     TRY_V(hipMemcpy(d_v, origins, vb, hipMemcpyHostToDevice));
     TRY_V(hipMemcpy(d_v + vn, directions, vb, hipMemcpyHostToDevice));
     TRY_V(hipMemcpy(d_v + 2 * vn, targets, vb, hipMemcpyHostToDevice));
@@ -2553,10 +2712,10 @@ static int unit_run(int device, const double *in_a, const double *in_b, int64_t 
     size_t vb = (size_t)n * 3 * sizeof(double);
     int rc = RT_OK;
     hipError_t e = hipSuccess;
-    if (in_a && (e = hipMalloc((void **)&d_a, vb)) == hipSuccess) e = hipMemcpy(d_a, in_a, vb, hipMemcpyHostToDevice);
-    if (e == hipSuccess && in_b && (e = hipMalloc((void **)&d_b, vb)) == hipSuccess) e = hipMemcpy(d_b, in_b, vb, hipMemcpyHostToDevice);
-    if (e == hipSuccess && out_a) e = hipMalloc(&d_oa, (size_t)n * out_a_bytes_per_ray);
-    if (e == hipSuccess && out_b) e = hipMalloc(&d_ob, (size_t)n * out_b_bytes_per_ray);
+    if (in_a && (e = rt_malloc(&d_a, vb)) == hipSuccess) e = hipMemcpy(d_a, in_a, vb, hipMemcpyHostToDevice);
+    if (e == hipSuccess && in_b && (e = rt_malloc(&d_b, vb)) == hipSuccess) e = hipMemcpy(d_b, in_b, vb, hipMemcpyHostToDevice);
+    if (e == hipSuccess && out_a) e = rt_malloc(&d_oa, (size_t)n * out_a_bytes_per_ray);
+    if (e == hipSuccess && out_b) e = rt_malloc(&d_ob, (size_t)n * out_b_bytes_per_ray);
     if (e == hipSuccess) {
         launch(d_a, d_b, (uint64_t)n, d_oa, d_ob, extra);
         e = hipDeviceSynchronize();
@@ -2579,7 +2738,7 @@ struct UnitExtra {
 
 static double *unit_params(const double *par, int n) {
     double *d = nullptr;
-    if (hipMalloc((void **)&d, n * sizeof(double)) != hipSuccess) return nullptr;
+    if (rt_malloc(&d, n * sizeof(double)) != hipSuccess) return nullptr;
     if (hipMemcpy(d, par, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
     return d;
 }

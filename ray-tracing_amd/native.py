@@ -16,7 +16,8 @@ LIB_PATH = os.path.join(_PKG, "csrc", "librt_amd.so")
 _LIB = None
 
 EXPORTS = ("rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_tile_pixels", "rt_tile_layout",
-           "rt_render", "rt_render_mean", "rt_render_device", "rt_sync_stats", "rt_trace", "rt_intersect", "rt_visibility",
+           "rt_render", "rt_render_mean", "rt_render_device", "rt_render_device_noalloc", "rt_noalloc_scratch_bytes",
+           "rt_debug_alloc_calls", "rt_sync_stats", "rt_trace", "rt_intersect", "rt_visibility",
            "rt_deinterleave_u8",
            "rt_initial_rays", "rt_unit_prim_intersect", "rt_unit_prim_normals", "rt_unit_slab_mask",
            "rt_bsp_build", "rt_bsp_stats_get", "rt_bsp_fetch", "rt_bsp_destroy", "rt_bsp_last_error",
@@ -49,6 +50,9 @@ def lib():
                                      C.POINTER(abi.Stats)]
         L.rt_render_device.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]
+        L.rt_render_device_noalloc.argtypes = L.rt_render_device.argtypes
+        L.rt_noalloc_scratch_bytes.restype = C.c_int64
+        L.rt_debug_alloc_calls.restype = C.c_int64
         L.rt_sync_stats.argtypes = [C.c_void_p, C.POINTER(abi.Stats)]
         L.rt_trace.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_void_p, C.POINTER(abi.Stats)]
@@ -167,6 +171,11 @@ class Context:
         """Enqueue a frame; outputs are raw device pointers (ints, 0 = not wanted); returns immediately."""
         _check(lib().rt_render_device(self._h, C.byref(params), C.c_void_p(d_rgb or None), C.c_void_p(d_rgb8 or None),
                                       C.c_void_p(d_ids or None), C.c_void_p(stream or None)), self._h)
+
+    def render_device_noalloc(self, params, d_rgb=0, d_rgb8=0, d_ids=0, stream=0):
+        """rt_render_device_noalloc: the same frame with all of its working memory in the library's static device array."""
+        _check(lib().rt_render_device_noalloc(self._h, C.byref(params), C.c_void_p(d_rgb or None), C.c_void_p(d_rgb8 or None),
+                                              C.c_void_p(d_ids or None), C.c_void_p(stream or None)), self._h)
 
     def sync_stats(self):
         st = abi.Stats()
