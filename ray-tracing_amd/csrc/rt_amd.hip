@@ -189,9 +189,11 @@ __device__ __noinline__ Hit nearest_hit_exact(const DScene &S, d3 o, d3 d) {
 __device__ __forceinline__ bool ray_is_tame(d3 o, d3 d) {
     // the float32 culling assumes finite coordinates well inside the float range and away from the
     // Background point (1e8,1e8,1e8); anything else takes the exact walk
+    // ... and so does a ray with an exactly zero direction component: if its origin lies in a node's bound plane the
+    // reference culls that node (0 * inf = NaN in Cube.cube_intersection_mask), which only the reference-order walk repeats
     double m = fmax(fmax(fabs(o.x), fabs(o.y)), fabs(o.z));
     double n = fmax(fmax(fabs(d.x), fabs(d.y)), fabs(d.z));
-    return (m < 1e7) && (n < 1e7) && (n > 1e-30);
+    return (m < 1e7) && (n < 1e7) && (n > 1e-30) && (d.x != 0) && (d.y != 0) && (d.z != 0);
 }
 
 // nearest hit, fast path with exact fallback (ties between different primitives, wild rays, non-kd trees)
@@ -529,7 +531,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
             const float D0 = -e0 * il, D1 = -e1 * il, D2 = -e2 * il;
             // util.get_orthonormal_vector: the branch is taken on the float64 value of D.z (Q7)
             const double az = fabs(dl.z), an = fabs(dl.x) + fabs(dl.y) + az;
-            bool delicate = !(an > 0.0) || !(an < 1e7) || !ray_is_tame(P, dl);
+            bool delicate = !(an > 0.0) || !(an < 1e7) || !ray_is_tame(P, mk3(1.0, 1.0, 1.0)) || !(an > 1e-30);
             float u0 = 1.0f, u1 = 1.0f, u2 = 0.0f;
             if (dl.z != 0.0) {
                 if (az < 1e-280 * an || fabsf(D2) < 1e-12f) delicate = true;   // D.z would underflow, or (1,1,u3) overflows float32
@@ -560,6 +562,16 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
             h0 = fmaf(RT_2M18, fabsf(cB0) + h0, h0) + 1e-5f;
             h1 = fmaf(RT_2M18, fabsf(cB1) + h1, h1) + 1e-5f;
             h2 = fmaf(RT_2M18, fabsf(cB2) + h2, h2) + 1e-5f;
+            // Some sample may share a coordinate with P (a shadow ray with an exactly zero direction component) and P lies
+            // in a bound plane of some node there: the reference culls that node for such a ray (on_node_plane), and the
+            // float64 queue repeats that; no filter verdicts for the pair.  (Under a light, in scenes built on round numbers.)
+            {
+                const bool z0 = fabsf(cB0) <= h0, z1 = fabsf(cB1) <= h1, z2 = fabsf(cB2) <= h2;
+                if (z0 || z1 || z2) {
+                    if ((z0 && on_node_plane(F, 0, (float)P.x)) || (z1 && on_node_plane(F, 1, (float)P.y)) || (z2 && on_node_plane(F, 2, (float)P.z)))
+                        delicate = true;
+                }
+            }
             uint2 *bs = lds_stack + threadIdx.x;
             uint32_t pcls = 0, n_eval = 0, n_atp = 0;      // whole-pair verdicts of the planes
 #pragma unroll
@@ -1405,6 +1417,7 @@ struct rt_ctx : FrameState {
     std::vector<hipEvent_t> prof_ev;     // RT_FLAG_PROFILE: [gen0, gen1, (i0,i1,s0,s1,h0,h1) per level ..., res0, res1]
     int prof_levels = -1;                // levels bracketed in the last frame, -1 = not profiled
     bool frame_pending = false;
+    bool counters_dirty = false;         // a voided frame left lit counts behind: clear them before the next frame
     bool last_noalloc = false;           // the last frame came through rt_render_device_noalloc: its queues cannot grow
     rt_render_params last{};
     int32_t last_sh = 0, last_rec = 0;
@@ -1726,6 +1739,21 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
         });
         if (!r2_ok) ok = false;
         if ((size_t)ns + nb >= (1u << 30)) ok = false;
+        for (int k = 0; k < 3; ++k) {
+            std::vector<float> cuts;
+            cuts.push_back((float)s->node_lo[k]);
+            cuts.push_back((float)s->node_hi[k]);
+            for (int i = 0; i < nn; ++i)
+                if (s->node_right[i] >= 0) {          // the children's shared bound on the split axis; their other bounds are the parent's
+                    const double *lhi = s->node_hi + 3 * (size_t)(i + 1), *rlo = s->node_lo + 3 * (size_t)s->node_right[i];
+                    if (lhi[k] != s->node_hi[3 * (size_t)i + k]) cuts.push_back((float)lhi[k]);
+                    if (rlo[k] != s->node_lo[3 * (size_t)i + k]) cuts.push_back((float)rlo[k]);
+                }
+            std::sort(cuts.begin(), cuts.end());
+            cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+            ctx->F.n_cuts[k] = (int32_t)cuts.size();
+            TRY_C(upload(ctx, ctx->scene_allocs, cuts, &ctx->F.cuts[k]));
+        }
         TRY_C(upload(ctx, ctx->scene_allocs, kn, &ctx->F.knodes));
         TRY_C(upload(ctx, ctx->scene_allocs, lf, &ctx->F.leaves));
         TRY_C(upload(ctx, ctx->scene_allocs, prim_entry, &ctx->F.prim_entry));
@@ -1973,7 +2001,18 @@ static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
     if (want_cap > 0xFFFFFFF0ull) return fail(ctx, RT_ERR_UNSUPPORTED, "ray queue would exceed 2^32 entries");
     const double want_qd = (double)want_cap * ctx->qgrowth;
     const uint32_t want_q = (uint32_t)(want_qd < 2147483647.0 ? want_qd : 2147483647.0);
-    if (ctx->cap >= want_cap && ctx->fb_slots >= slots && ctx->beam_queue_cap >= want_q) return RT_OK;
+    if (ctx->cap >= want_cap && ctx->fb_slots >= slots && ctx->beam_queue_cap >= want_q) {
+        if (ctx->counters_dirty) {
+            // the last frame was voided by a queue overflow: its shading kernels returned early and left lit counts behind
+            // (k_shade clears them only as it consumes them); a smaller frame that fits the old buffers must not see them
+            HIP_TRY(ctx, hipDeviceSynchronize());
+            if (int rc = init_frame_counters(ctx, *ctx, ctx->stream)) return rc;
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->counters_dirty = false;
+        }
+        return RT_OK;
+    }
+    ctx->counters_dirty = false;
     HIP_TRY(ctx, hipDeviceSynchronize());   // rare: buffers of an in-flight frame are about to be replaced
     free_frame(ctx);
     const uint64_t cap = want_cap;
@@ -2465,6 +2504,7 @@ extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
     }
     if (c.overflow) {
         // the next frame gets larger queues: the one that ran out
+        if (!ctx->last_noalloc) ctx->counters_dirty = true;
         if (ctx->last_noalloc) return fail(ctx, RT_ERR_QUEUE_OVERFLOW, "secondary-ray queue overflow in a no-alloc frame (its queues hold 2 x the pixel slots and cannot grow); nothing valid was written");
         if (c.overflow_q && ctx->beam_queue_cap < 0x7fffffffu) ctx->qgrowth *= 8.0;
         else ctx->growth *= 2.0;

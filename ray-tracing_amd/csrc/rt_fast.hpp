@@ -48,7 +48,25 @@ struct FastScene {
     float extent;                   // max |coordinate| of the root box, rounded up
     int32_t depth;                  // tree depth = stack entries needed per lane
     int32_t ok;                     // 0: tree is not an exact kd tiling (or too deep) -> use the exact walk
+    // every cut location and root bound of the tree, per axis, rounded to float32, sorted, distinct (on_node_plane)
+    const float *cuts[3];
+    int32_t n_cuts[3];
 };
+
+// Could coordinate v (float64 -> float32) on axis ax be EXACTLY a bound of some node?  A ray that starts in such a plane
+// with an exactly zero direction component along ax is not served by "tree walk == brute force": the reference's slab
+// test evaluates 0 * inf = NaN there and culls the node with its whole subtree (Cube.py:120-136, BSPNode.py:132).
+// Equality in float32 is necessary for equality in float64, so a "no" is certain.
+__device__ __forceinline__ bool on_node_plane(const FastScene &F, int ax, float v) {
+    const float *a = F.cuts[ax];
+    int lo = 0, hi = F.n_cuts[ax];
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo < F.n_cuts[ax] && a[lo] == v;
+}
 
 struct FastState {
     Hit best;

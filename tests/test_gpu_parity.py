@@ -91,9 +91,36 @@ def test_intersect_incoherent_rays(gpu_ctx, oracle, tag):
     assert eq_nan(pts, opts)
 
 
+def test_rays_in_a_node_plane_are_culled_like_the_reference(gpu_ctx, oracle):
+    """Origin exactly on a node bound with direction exactly 0 along that axis: the reference culls the node
+    (0 * inf = NaN, Cube.py:120-136).  Golden made by the reference on every node of the mirror-symmetric scene."""
+    g, _ = golden("secondary_oncut")
+    ctx = gpu_ctx("oncut")
+    pts, ids = ctx.intersect(g["origins"], g["directions"])
+    assert np.array_equal(ids, g["ids"].astype(np.int64))
+    assert np.allclose(pts, g["points"], rtol=1e-12, atol=1e-12, equal_nan=True)
+    opts, oids, _ = oracle.intersect(load_scene("oncut")["packed"], g["origins"], g["directions"])
+    assert np.array_equal(ids, oids) and eq_nan(pts, opts)
+    # the any-hit query on the same rays: lit <=> nearest hit within 1e-6 of the target
+    tg = np.where((g["ids"] != 0)[:, None], g["points"], g["origins"] + g["directions"])   # a miss: some point on the ray
+    lit = ctx.visibility(g["origins"], g["directions"], tg)
+    assert np.array_equal(lit, g["ids"] != 0)
+    for w, h in ((65, 39), (9, 5)):
+        gp, m = golden("primary_oncut_%dx%d" % (w, h))
+        out = ctx.render(abi.render_params(w, h, sh_rays=1, rec_max=0, jitter=False), want_rgb=False)
+        assert np.array_equal(out["ids"], gp["ids"].astype(np.int32))
+        # hashed jitter on: default path == reference-order walk == per-ray float64 path, bit for bit
+        frames = [ctx.render(abi.render_params(w, h, sh_rays=3, jitter=True, seed=9, flags=f))
+                  for f in (0, abi.RT_FLAG_EXACT_TRAVERSAL, abi.RT_FLAG_NO_BEAM)]
+        for fr in frames[1:]:
+            assert np.array_equal(fr["rgb"], frames[0]["rgb"]) and np.array_equal(fr["ids"], frames[0]["ids"])
+
+
 # ------------------------------------------------------------------ frames, deterministic
 FRAMES = ["pool_64x36_s1", "pool_160x90_s5", "pool_1920x1080_s1", "original_100x100", "original_500x500",
-          "small_160x100", "small_64x40_s3_r6", "synth400_160x90_s2_r3"]
+          "small_160x100", "small_64x40_s3_r6", "synth400_160x90_s2_r3",
+          # camera, a light and the root cut on one plane, odd width: rays with direction.x == 0 from origins on a node bound
+          "oncut_65x39_s1", "oncut_65x39_s3", "oncut_43x25_s2_r1"]
 
 
 @pytest.mark.parametrize("name", FRAMES)
@@ -265,9 +292,9 @@ def test_fast_intersect_axis_parallel_and_degenerate_rays(gpu_ctx, oracle):
     o = rng.uniform(f.lo[0] - 1, f.hi[0] + 1, (n, 3))
     d = np.zeros((n, 3))
     d[np.arange(n), rng.integers(0, 3, n)] = rng.choice([-1.0, 1.0], n)      # axis parallel
-    d[::3] += rng.normal(size=(len(d[::3]), 3)) * 1e-3                          # nearly axis parallel
-    cuts = f.hi[1:40, :]                                                        # origins exactly on node planes
-    o[:117:3] = cuts.reshape(-1, 3)[:39]
+    d[1::3] += rng.normal(size=(len(d[1::3]), 3)) * 1e-3                        # nearly axis parallel
+    cuts = f.hi[1:40, :]                                                        # origins exactly on node planes,
+    o[:117:3] = cuts.reshape(-1, 3)[:39]                                        # directions with two exact zeros
     d /= np.linalg.norm(d, axis=-1, keepdims=True)
     pts, ids = gpu_ctx("small").intersect(o, d)
     opts, oids, _ = oracle.intersect(sc["packed"], o, d)
@@ -414,10 +441,8 @@ def test_rays_of_overflowing_pairs_walk_or_expand_to_the_same_frame(gpu_ctx, kin
         assert out["stats"]["rays"] == exact["stats"]["rays"]
 
 
-def test_queue_overflow_grows_the_queues_and_renders_again(oracle, tmp_path):
-    """Every hit in this scene spawns a through-ray AND a mirror ray, so level L holds up to 2^L rays per pixel:
-    the queues (2 x the primary slots to begin with) overflow, rt_sync_stats reports it, the growth factor doubles and
-    rt_render renders again until the frame fits.  The frame that comes out equals the oracle's."""
+def _glass_scene(tmp_path):
+    """Every hit in this scene spawns a through-ray AND a mirror ray, so level L holds up to 2^L rays per pixel."""
     from ray_tracing_amd import scene_pack
     from Parser import parse_scene_file
     from BSPNode import BSPNode
@@ -430,7 +455,13 @@ def test_queue_overflow_grows_the_queues_and_renders_again(oracle, tmp_path):
     p = tmp_path / "glass.txt"
     p.write_text("\n".join(text) + "\n")
     cam, st, _o, surfaces, mats, lights = parse_scene_file(str(p))
-    packed = scene_pack.pack_scene(surfaces, mats, lights, cam, st, BSPNode.build_bsp_tree(surfaces))
+    return scene_pack.pack_scene(surfaces, mats, lights, cam, st, BSPNode.build_bsp_tree(surfaces))
+
+
+def test_queue_overflow_grows_the_queues_and_renders_again(oracle, tmp_path):
+    """The queues (2 x the primary slots to begin with) overflow, rt_sync_stats reports it, the growth factor doubles and
+    rt_render renders again until the frame fits.  The frame that comes out equals the oracle's."""
+    packed = _glass_scene(tmp_path)
     prm = abi.render_params(96, 54, jitter=True, seed=3)
     ref = oracle.render(packed, prm)
     with native.Context(packed) as ctx:
@@ -442,6 +473,24 @@ def test_queue_overflow_grows_the_queues_and_renders_again(oracle, tmp_path):
         assert np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
         for key in ("primary_rays", "shadow_rays", "reflect_rays", "transmit_rays", "hits"):
             assert out["stats"][key] == ref["counters"][key], key
+
+
+def test_a_voided_frame_leaves_nothing_behind_for_a_smaller_one(oracle, tmp_path):
+    """A frame voided by a queue overflow returns early from its shading kernels; the lit counters it had already
+    filled must not leak into the next frame when that one is small enough to reuse the buffers as they are."""
+    packed = _glass_scene(tmp_path)
+    with native.Context(packed) as ctx:
+        big = abi.render_params(192, 108, jitter=True, seed=3)
+        ctx.render_device(big)
+        with pytest.raises(native.NativeError) as e:
+            ctx.sync_stats()
+        assert e.value.code == abi.RT_ERR_QUEUE_OVERFLOW
+        small = abi.render_params(48, 27, jitter=True, seed=3)      # (2 x growth) x 1/16 of the slots: no reallocation
+        out = ctx.render(small)
+    ref = oracle.render(packed, small)
+    assert np.array_equal(out["ids"], ref["ids"])
+    assert np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
+    assert out["stats"]["shadow_rays"] == ref["counters"]["shadow_rays"]
 
 
 def test_mixed_lattice_with_transparency_equals_exact_walk(oracle):

@@ -63,6 +63,26 @@ def test_shading_terms(oracle):
     assert np.allclose(spec, g["specular"], rtol=1e-13, atol=1e-300)
 
 
+def test_rays_in_a_node_plane_are_culled_like_the_reference(oracle):
+    """direction component exactly 0 with the origin exactly on a bound of a node: the reference's slab test yields
+    0 * inf = NaN and culls the node (Cube.py:120-136), so its tree walk is NOT brute force for such rays."""
+    g, meta = golden("secondary_oncut")
+    ps = load_scene("oncut")["packed"]
+    pts, ids, _ = oracle.intersect(ps, g["origins"], g["directions"])
+    assert np.array_equal(ids, g["ids"])
+    assert np.allclose(pts, g["points"], rtol=1e-12, atol=1e-12, equal_nan=True)
+    for w, h in ((65, 39), (9, 5)):
+        gp, m = golden("primary_oncut_%dx%d" % (w, h))
+        assert m["zero_dx"] == h and m["q4_events"] == 0          # the whole centre column has direction.x == 0
+        src, dirs = oracle.initial_rays(ps, w, h)
+        pts, ids, _ = oracle.intersect(ps, src, dirs)
+        assert np.array_equal(ids, gp["ids"])
+        assert np.allclose(pts, gp["points_q4fix"], rtol=1e-12, atol=1e-12)
+        # the centre column sees only the ground plane although a sphere stands in front of it
+        col = ids.reshape(h, w)[:, w // 2]
+        assert set(col.tolist()) <= {0, 1}
+
+
 @pytest.mark.parametrize("tag,w,h", [("pool", 1920, 1080), ("original", 500, 500), ("small", 320, 200),
                                      ("synth400", 320, 180)])
 def test_primary_ids_and_points(oracle, tag, w, h):
@@ -97,7 +117,8 @@ def test_visibility_mask(oracle, tag):
 
 
 FRAMES = ["pool_64x36_s1", "pool_160x90_s5", "pool_1920x1080_s1", "original_100x100", "original_500x500",
-          "small_160x100", "small_64x40_s3_r6", "synth400_160x90_s2_r3"]
+          "small_160x100", "small_64x40_s3_r6", "synth400_160x90_s2_r3",
+          "oncut_65x39_s1", "oncut_65x39_s3", "oncut_43x25_s2_r1"]
 
 
 @pytest.mark.parametrize("name", FRAMES)

@@ -143,6 +143,39 @@ def small_mixed(seed: int = 7, n: int = 200) -> str:
     return out.getvalue()
 
 
+def on_cut_symmetric() -> str:
+    """A scene that is mirror-symmetric about x = 0 with the camera and one light ON that plane: the root's cut lies at
+    x = 0 exactly, the centre column of an odd-width frame has direction.x == 0 exactly, and so have the shadow rays from
+    the on-axis light to points of that column.  The reference then evaluates 0 * inf = NaN in its slab test
+    (Cube.py:120-136) and culls both children of the root for those rays - an input where "the tree walk equals brute
+    force" does not hold.  Deterministic (no random numbers)."""
+    out = io.StringIO()
+    out.write("# mirror-symmetric scene: camera, light 1 and the root cut on the plane x = 0\n")
+    out.write("cam 0 2 -8 0 0 4 0 1 0 1.5 1\n")
+    out.write("set 0.25 0.35 0.5 3 3\n")
+    out.write("mtl 0.8 0.3 0.2 0.8 0.8 0.8 0.25 0.25 0.25 25 0\n")
+    out.write("mtl 0.2 0.7 0.3 0.5 0.5 0.5 0 0 0 9 0\n")
+    out.write("mtl 0.3 0.4 0.9 0.9 0.9 0.9 0 0 0 40 0.5\n")
+    out.write("mtl 0.6 0.6 0.55 0.1 0.1 0.1 0.1 0.1 0.1 2 0\n")
+    out.write("pln 0 1 0 -1 4\n")
+    k = 0
+    for iz in range(6):
+        for ix, x in enumerate((0.75, 1.75, 2.75)):
+            y = -1.0 + 0.375 + 0.25 * ((ix + iz) % 3)
+            r = 0.25 + 0.125 * ((ix + 2 * iz) % 2)
+            for sx in (-1.0, 1.0):
+                if (ix + iz) % 4 == 3:
+                    out.write("box %r %r %r %r %d\n" % (sx * x, y, float(iz), 2 * r, 1 + k % 3))
+                else:
+                    out.write("sph %r %r %r %r %d\n" % (sx * x, y, float(iz), r, 1 + k % 3))
+            k += 1
+    out.write("sph 0 -0.25 2.5 0.5 1\n")          # straddles the plane x = 0: geometrically in front of the centre column
+    out.write("box 0 -0.5 5 0.75 2\n")
+    out.write("lgt 0 7 1 0.9 0.9 0.85 1 0.8 1.5\n")
+    out.write("lgt -4 5 -3 0.4 0.4 0.5 1 0.6 1\n")
+    return out.getvalue()
+
+
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("kind", choices=["synth", "mixed", "small"])

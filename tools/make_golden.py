@@ -395,8 +395,8 @@ FRAMES = [
 ]
 
 
-def g_frames(out, scenes, which=None):
-    for name, tag, w, h, sh, rec in FRAMES:
+def g_frames(out, scenes, which=None, frames=None):
+    for name, tag, w, h, sh, rec in (frames or FRAMES):
         if which and name not in which:
             continue
         img, meta = render(scenes[tag], w, h, sh=sh, rec=rec, jitter=False, fix_q4=False)
@@ -409,6 +409,46 @@ def g_frames(out, scenes, which=None):
         if w * h <= 20000:
             arrays["rgb_f64_q4fix"] = img_f          # unclipped float64, small frames only
         save(out, "frame_" + name + "_nojitter", meta, **arrays)
+
+
+def g_oncut(out, scenes):
+    """Rays with an exactly zero direction component whose origin lies exactly on a node bound (the reference's
+    0 * inf = NaN cull, Cube.py:120-136): crafted batches through intersect_vectorize, primary hit ids and
+    deterministic frames of the mirror-symmetric scene at odd widths."""
+    cam, st, surfaces, mats, lights, bsp = load_scene(scenes["oncut"])
+    t = dump_tree(bsp)
+    rng = np.random.default_rng(21)
+    lo, hi = t["lo"], t["hi"]
+    O, D = [], []
+    for i in range(len(lo)):                      # every node: origins on each of its six bound planes
+        for ax in range(3):
+            for bound in (lo[i, ax], hi[i, ax]):
+                for _ in range(3):
+                    o = rng.uniform(lo[0] - 1.0, hi[0] + 1.0)
+                    o[ax] = bound
+                    d = rng.normal(size=3)
+                    d[ax] = 0.0                   # stays exactly zero under the normalisation
+                    if rng.uniform() < 0.3:
+                        d[(ax + 1) % 3] = 0.0
+                    d /= np.linalg.norm(d)
+                    O.append(o); D.append(d)
+    O, D = np.array(O), np.array(D)
+    with q4_mode(True):
+        pts, ids = bsp.intersect_vectorize(ray_sources=O, ray_directions=D)
+    save(out, "secondary_oncut", dict(n=int(len(O)), hits=int((ids != 0).sum())), origins=O, directions=D, points=pts,
+         ids=ids.astype(np.int32))
+    for w, h in ((65, 39), (9, 5)):
+        src, dirs = ref_rf.get_initial_rays(cam, image_width=w, image_height=h)
+        with q4_mode(False) as q4:
+            pts, ids = bsp.intersect_vectorize(ray_sources=src, ray_directions=dirs)
+        with q4_mode(True):
+            pts_f, ids_f = bsp.intersect_vectorize(ray_sources=src, ray_directions=dirs)
+        save(out, "primary_oncut_%dx%d" % (w, h),
+             dict(width=w, height=h, q4_events=q4.events, ids_differ_q4=int((ids != ids_f).sum()),
+                  zero_dx=int((dirs[:, 0] == 0).sum())),
+             ids=ids.astype(np.int16), ids_q4fix=ids_f.astype(np.int16), points_q4fix=pts_f)
+    g_frames(out, scenes, None, [("oncut_65x39_s1", "oncut", 65, 39, 1, None), ("oncut_65x39_s3", "oncut", 65, 39, 3, None),
+                                 ("oncut_43x25_s2_r1", "oncut", 43, 25, 2, 1)])
 
 
 def g_stochastic(out, scenes, K=32):
@@ -466,7 +506,8 @@ def main():
                 g.write(f.read())
         scenes[tag] = dst
     gen = {"small": lambda: gen_scene.small_mixed(7, 200),
-           "synth400": lambda: gen_scene.synth_spheres(20, 1234, 2, 3)}
+           "synth400": lambda: gen_scene.synth_spheres(20, 1234, 2, 3),
+           "oncut": gen_scene.on_cut_symmetric}
     for tag, fn in gen.items():
         dst = os.path.join(sc_dir, tag + ".txt")
         if not os.path.exists(dst):
@@ -477,7 +518,7 @@ def main():
     steps = dict(rays=g_rays, prims=g_prims, bsp=g_bsp, shadow_grid=g_shadow_grid, shade_terms=g_shade_terms,
                  secondary=g_secondary, visibility=g_visibility, primary=g_primary, counts=g_counts,
                  frames=lambda o, s: g_frames(o, s, set(a.frames.split(",")) if a.frames else None),
-                 stochastic=lambda o, s: g_stochastic(o, s, a.K))
+                 stochastic=lambda o, s: g_stochastic(o, s, a.K), oncut=g_oncut)
     only = [x for x in a.only.split(",") if x]
     for name, fn in steps.items():
         if only and name not in only:
