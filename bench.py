@@ -14,9 +14,13 @@ inputs (scene, BSP tree) resident in HBM before the timed region.
 value = rays handed to the nearest-hit query per second, counted exactly as the
 reference counts them (every ray given to BSPNode.intersect_vectorize), whole job.
 
-Rank 0 prints ONE JSON line with the roofline of the dominant kernel family (soft shadows:
-k_beam_setup + k_shadow_beam + k_shadow_queue, timed with HIP events on the launch stream)
-and the CPU baseline (the float64 oracle, timed on a bounded sub-sampled frame).
+Rank 0 prints ONE JSON line.  `roofline` is about the frame's dominant kernel, k_beam_setup: its launches are timed live
+with HIP events on their stream (profile frames after the timed loop), and the floating-point work it EXECUTES per frame
+(hardware counters of this very workload and tree, profiles/r02_pmc_<workload>.json, made by tools/pmc_roofline.sh) is
+divided by that time: a fraction of the FP32 vector peak that cannot exceed 1.  The rate of the REFERENCE's algorithmic
+work is printed beside it under its own name - the pipeline skips most of that work (whole-pair
+verdicts), so it is no statement about the hardware.  `cpu_baseline`: the float64 oracle on a bounded sub-sampled frame,
+on all host threads and on one.
 """
 import argparse
 import json
@@ -77,11 +81,48 @@ def algorithmic_flops(cnt, n_lights, n_planes):
     return frame, shadow
 
 
+def profile_file(workload, W, H, world):
+    """committed hardware-counter summary of this workload (None when there is none for this shape)"""
+    name = {"synth10k": "synth10k_1920x1080"}.get(workload) if (W, H, world) == (1920, 1080, 1) else None
+    path = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % name) if name else None
+    if path and os.path.exists(path):
+        with open(path) as f:
+            return json.load(f), os.path.relpath(path, ROOT)
+    return None, None
+
+
+def time_frames(ctx, abi, native, torch, stream, W, H, frames, warm, **kw):
+    """mean device-side ms of `frames` frames of one context on `stream` (HIP events around the loop)"""
+    n = native.tile_pixels(abi.render_params(W, H, **kw))
+    buf = torch.empty(n * 3, dtype=torch.uint8, device=stream.device)
+    for _ in range(4):
+        try:
+            with torch.cuda.stream(stream):
+                ctx.render_device(abi.render_params(W, H, seed=1, **kw), d_rgb8=buf.data_ptr(), stream=stream.cuda_stream)
+            ctx.sync_stats()
+            break
+        except native.NativeError as e:
+            if e.code != abi.RT_ERR_QUEUE_OVERFLOW:
+                raise
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(stream):
+        for i in range(warm):
+            ctx.render_device(abi.render_params(W, H, seed=10 + i, **kw), d_rgb8=buf.data_ptr(), stream=stream.cuda_stream)
+        e0.record(stream)
+        for i in range(frames):
+            ctx.render_device(abi.render_params(W, H, seed=100 + i, **kw), d_rgb8=buf.data_ptr(), stream=stream.cuda_stream)
+        e1.record(stream)
+    torch.cuda.synchronize()
+    if ctx.voided_frames(reset=True):
+        raise SystemExit("a timed frame was voided by a queue overflow")
+    return e0.elapsed_time(e1) / frames
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="synth10k")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
@@ -91,6 +132,7 @@ def main():
     ap.add_argument("--ingest", choices=("native", "python"), default="native",
                     help="scene text -> tables -> tree: C++ tokenizer + GPU tree build, or Python objects + host build")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the pool.txt frame times and the render / gather split")
     ap.add_argument("--cpu-sample-div", type=int, default=2, help="CPU baseline renders (W/div)x(H/div)")
     args = ap.parse_args()
 
@@ -137,18 +179,35 @@ def main():
                                  world=world, flags=flags)
 
     npix = native.tile_pixels(params(0))
-    local = torch.empty(npix * 3, dtype=torch.uint8, device=dev)
+    # two packed tile buffers: the gather of frame i (communication stream) runs beside the rendering of frame i + 1
+    local = [torch.empty(npix * 3, dtype=torch.uint8, device=dev) for _ in range(2)]
     image = torch.empty(H * W * 3, dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
     stream = torch.cuda.Stream(device=dev)
+    comm = torch.cuda.Stream(device=dev) if world > 1 else None
+    rendered = [torch.cuda.Event() for _ in range(2)]
+    gathered_ev = [torch.cuda.Event() for _ in range(2)]
+
+    def render(i):
+        b = i & 1
+        with torch.cuda.stream(stream):
+            if world > 1 and i >= 2:
+                stream.wait_event(gathered_ev[b])          # the gather of frame i - 2 has read this buffer
+            ctx.render_device(params(1000 + i), d_rgb8=local[b].data_ptr(), stream=stream.cuda_stream)
+            rendered[b].record(stream)
+
+    def gather(i):
+        b = i & 1
+        with torch.cuda.stream(comm):
+            comm.wait_event(rendered[b])
+            got = gather_packed(local[b], rank, world, dst=0)                # the frame's one exchange step
+            if rank == 0:
+                ctx.deinterleave_u8(params(1000 + i), got.data_ptr(), npix * 3, image.data_ptr(), stream=comm.cuda_stream)
+            gathered_ev[b].record(comm)
 
     def step(i):
-        with torch.cuda.stream(stream):
-            p = params(1000 + i)
-            ctx.render_device(p, d_rgb8=local.data_ptr(), stream=stream.cuda_stream)
-            if world > 1:
-                gathered = gather_packed(local, rank, world, dst=0)          # the frame's one exchange step
-                if rank == 0:
-                    ctx.deinterleave_u8(p, gathered.data_ptr(), npix * 3, image.data_ptr(), stream=stream.cuda_stream)
+        render(i)
+        if world > 1:
+            gather(i)
 
     def fence():
         torch.cuda.synchronize()
@@ -161,12 +220,13 @@ def main():
     for _ in range(6):
         try:
             with torch.cuda.stream(stream):
-                ctx.render_device(params(999), d_rgb8=local.data_ptr(), stream=stream.cuda_stream)
+                ctx.render_device(params(999), d_rgb8=local[0].data_ptr(), stream=stream.cuda_stream)
             ctx.sync_stats()
             break
         except native.NativeError as e:
-            if e.code != -5:
+            if e.code != abi.RT_ERR_QUEUE_OVERFLOW:
                 raise
+    ctx.voided_frames(reset=True)
     for i in range(args.warmup):
         step(i)
     fence()
@@ -176,22 +236,60 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     st = ctx.sync_stats()                       # counters of the last frame (ray counts do not depend on the seed)
+    voided = ctx.voided_frames(reset=True)      # counted on the device over ALL frames since the reset above
     el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     rays = torch.tensor([float(st["rays"])], dtype=torch.float64, device=red_dev)
+    bad = torch.tensor([float(voided)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+        dist.all_reduce(bad, op=dist.ReduceOp.SUM)
+    if bad.item() > 0:
+        raise SystemExit("%d timed frame(s) were voided by a queue overflow: the measurement is invalid" % int(bad.item()))
     elapsed = float(el.item())
     rays_per_frame = float(rays.item())
 
-    # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream ----
+    # ---- N > 1: where a step's time goes - rendering alone, gather + de-interleave alone (outside the timed region) ----
+    split = None
+    if world > 1 and not args.no_extra:
+        k = max(10, args.steps // 4)
+        fence()
+        t1 = time.perf_counter()
+        for i in range(k):
+            render(i + 2)                       # (i + 2: the buffers' gather events of the loop above are long past)
+        fence()
+        t_render = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        for i in range(k):
+            gather(i)
+        fence()
+        t_gather = time.perf_counter() - t1
+        tt = torch.tensor([t_render / k, t_gather / k], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        split = {"render_ms_per_frame_max_over_ranks": round(float(tt[0]) * 1e3, 3),
+                 "gather_deinterleave_ms_per_frame": round(float(tt[1]) * 1e3, 3), "frames": k,
+                 "note": "the timed loop overlaps the two (double-buffered packed tiles, gather on its own stream)"}
+
+    # ---- the dominant kernel, timed live with HIP events on its launch stream (profile frames: levels in sequence) ----
     roofline = None
     cpu_baseline = None
     prof = None
+    extra = None
     if rank == 0:
-        with torch.cuda.stream(stream):
-            ctx.render_device(params(1000, flags=abi.RT_FLAG_PROFILE), d_rgb8=local.data_ptr(), stream=stream.cuda_stream)
-        prof = ctx.sync_stats()
+        n_prof = 5
+        acc = None
+        for i in range(n_prof):
+            with torch.cuda.stream(stream):
+                ctx.render_device(params(1000 + i, flags=abi.RT_FLAG_PROFILE), d_rgb8=local[0].data_ptr(), stream=stream.cuda_stream)
+            p = ctx.sync_stats()
+            if acc is None:
+                acc = dict(p)
+            else:
+                for key in ("ms_total", "ms_gen", "ms_intersect", "ms_shadow", "ms_shade", "ms_resolve", "ms_beam_setup"):
+                    acc[key] += p[key]
+        prof = acc
+        for key in ("ms_total", "ms_gen", "ms_intersect", "ms_shadow", "ms_shade", "ms_resolve", "ms_beam_setup"):
+            prof[key] /= n_prof
     if world > 1:
         dist.barrier()
 
@@ -216,41 +314,58 @@ def main():
         shadow_flops = flops_per_shadow_ray * prof["shadow_rays"]
         frame_flops = flops_per_ray * prof["rays"]
         ms_shadow = prof["ms_shadow"]
-        achieved = shadow_flops / (ms_shadow * 1e-3) / 1e12 if ms_shadow > 0 else 0.0
-        # HBM-side traffic of the same kernels: a committed rocprofv3 --pmc measurement of this workload
-        # (tools/pmc_traffic.sh -> profiles/r01_q_traffic.json); counters cannot be read from inside this process
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_q_traffic.json")
-        if args.workload == "synth10k" and world == 1 and (W, H) == (1920, 1080) and os.path.exists(tfile):
-            with open(tfile) as f:
-                traffic = json.load(f)["soft_shadow_family"]["hbm_bytes_per_frame_upper"]
-        # hardware counters of the same workload (committed rocprofv3 --pmc run): the share of VALU issue slots actually used
-        valu_share = None
-        vfile = os.path.join(ROOT, "profiles", "r01_p_valu_share.json")
-        if args.workload == "synth10k" and os.path.exists(vfile):
-            with open(vfile) as f:
-                vs = json.load(f)["kernels"]
-            valu_share = {"k_beam_setup": vs["k_beam_setup<false,false>"]["valu"], "k_shadow_beam": vs["k_shadow_beam"]["valu"],
-                          "k_intersect_camera_pass": vs["k_intersect<true,true>"]["valu"], "source": "profiles/r01_p_valu_share.json"}
+        ms_kernel = prof["ms_beam_setup"]
+        launches = prof["beam_setup_launches"]
+        pmc, pmc_path = profile_file(args.workload, W, H, world)
+        kname = next((k for k in (pmc["kernels"] if pmc else {}) if k.startswith("k_beam_setup")), None)
+        executed = pmc["kernels"][kname]["executed_flop_per_frame"] if kname else None
+        achieved = executed / (ms_kernel * 1e-3) / 1e12 if (executed and ms_kernel > 0) else None
         roofline = {
-            "bound": "valu", "kernel": "soft shadows: k_beam_setup + k_shadow_beam + k_shadow_queue", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": traffic,
-            "traffic_unit": "HBM bytes per frame of the soft-shadow kernels (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_q_traffic.json)",
-            "achieved_is": "algorithmic flops of the reference's per-ray traversals / measured kernel time (DESIGN.md section 5)",
-            "launches": prof["launches_per_family"], "kernel_ms_per_frame": round(ms_shadow, 3),
-            "valu_issue_share_measured": valu_share,
-            "algorithmic_flops_per_shadow_ray": round(flops_per_shadow_ray, 1),
-            "frame": {"algorithmic_flops_per_ray": round(flops_per_ray, 1),
-                      "achieved_tflops": round(frame_flops / (prof["ms_total"] * 1e-3) / 1e12, 3),
-                      "ms": {k: round(prof[k], 3) for k in ("ms_total", "ms_gen", "ms_intersect", "ms_shadow",
-                                                            "ms_shade", "ms_resolve")}},
+            "bound": "valu", "kernel": kname or "k_beam_setup",
+            "achieved": round(achieved, 3) if achieved is not None else None, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4) if achieved is not None else None,
+            "traffic": pmc["kernels"][kname].get("hbm_bytes_per_frame") if kname else None,
+            "traffic_unit": "HBM-side bytes of the kernel's launches of one frame (2 x FETCH_SIZE + WRITE_SIZE)",
+            "achieved_is": "floating-point operations the kernel EXECUTES per frame (hardware counters: ADD + MUL + TRANS + 2 FMA, "
+                           "float32 and float64, x active lanes; %s, tree %s) / its launches' duration measured in this run "
+                           "(HIP events on the launch stream, mean of 5 profile frames)" % (pmc_path, pmc["tree"] if pmc else None),
+            "kernel_ms_per_frame": round(ms_kernel, 4), "launches_per_frame": launches,
+            "avg_launch_ms": round(ms_kernel / launches, 4) if launches else None,
+            "executed_flop_per_frame": executed,
+            "valu_issue_share": pmc["kernels"][kname].get("valu_issue_share") if kname else None,
+            "lanes_active": pmc["kernels"][kname].get("lanes_active") if kname else None,
+            "reference_work_rate": {
+                "what": "algorithmic flops of the reference's per-ray traversals (SURVEY 8d, counted by the oracle) / time of all "
+                        "soft-shadow kernels; most of that work is never executed (whole-pair verdicts) - not a hardware rate",
+                "soft_shadow_tflops": round(shadow_flops / (ms_shadow * 1e-3) / 1e12, 3) if ms_shadow > 0 else None,
+                "algorithmic_flops_per_shadow_ray": round(flops_per_shadow_ray, 1),
+                "algorithmic_flops_per_ray": round(flops_per_ray, 1),
+                "frame_tflops": round(frame_flops / (prof["ms_total"] * 1e-3) / 1e12, 3)},
+            "frame_ms_levels_in_sequence": {k: round(prof[k], 3) for k in ("ms_total", "ms_gen", "ms_intersect", "ms_shadow",
+                                                                            "ms_shade", "ms_resolve")},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:
+            d1 = div * 4
+            s1 = abi.render_params(max(8, W // d1), max(8, H // d1), sh_rays=args.sh_rays, rec_max=args.rec_max, jitter=jitter, seed=1000)
+            c1 = time.perf_counter()
+            one = orc.render(scene.packed, s1, threads=1, want_f64=False)
+            one_s = time.perf_counter() - c1
             cpu_baseline = {"value": round(cnt["rays"] / cpu_s / 1e6, 3), "unit": "Mrays/s", "cores": threads,
                             "kind": "port",
                             "sample": "oracle/oracle.cpp (float64 restatement), same scene and settings at %dx%d "
-                                      "(1/%d of the pixels), %d rays in %.2f s" % (sw, sh_, div * div, cnt["rays"],
-                                                                                  cpu_s)}
+                                      "(1/%d of the pixels), %d rays in %.2f s" % (sw, sh_, div * div, cnt["rays"], cpu_s),
+                            "one_core": {"value": round(one["counters"]["rays"] / one_s / 1e6, 3), "unit": "Mrays/s", "cores": 1,
+                                         "sample": "%dx%d, %d rays in %.2f s" % (max(8, W // d1), max(8, H // d1),
+                                                                                one["counters"]["rays"], one_s)}}
+        if not args.no_extra and world == 1:
+            # the configuration BASELINE's >= 1000 x target is quoted on: pool.txt at 1920x1080 (reference: 37.3 s at s = 1)
+            pool, _ = build_scene("pool", args.ingest, gpu_index)
+            with native.Context(pool.packed, device=gpu_index) as pctx:
+                p1 = time_frames(pctx, abi, native, torch, stream, 1920, 1080, 60, 10, sh_rays=1, jitter=False)
+                p5 = time_frames(pctx, abi, native, torch, stream, 1920, 1080, 60, 10, sh_rays=5, jitter=True)
+            extra = {"pool_1920x1080_s1_nojitter_ms": round(p1, 3), "pool_1920x1080_s5_ms": round(p5, 3),
+                     "reference_numpy_pool_1920x1080_s1_s": 37.3, "speedup_vs_reference_s1": round(37.3e3 / p1, 0),
+                     "note": "device-side frame time (HIP events around 60 frames after 10); reference time from BASELINE.md (build container, 1 core)"}
 
     if rank == 0:
         value = rays_per_frame * args.steps / elapsed / 1e6
@@ -262,19 +377,24 @@ def main():
             ingest_info.update(parse_ms=round(scene.timing["parse_ms"], 1), tree_ms=round(scene.timing["tree_ms"], 1),
                                tree_device_ms=round(scene.timing["tree_device_ms"], 2))
         line = {
-            "metric": "Mrays/s (rays handed to the nearest-hit query, whole job); frame time = ms_per_step",
+            "metric": "Mrays/s (reference-equivalent rays: every ray the reference hands to its nearest-hit query, whole job); frame time = ms_per_step",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
+            "scaling": "strong" if world > 1 else "single GPU", "vs_baseline": None,
             "dtype": "f64 (decisions, hit points, shading); f32 filtered predicates with f64 fallback", "data": "synthetic",
             "config": {"workload": "%s %dx%d, %dx%d shadow rays, recursion %d, jitter %s" % (
                 args.workload, W, H, sh_used, sh_used, rec_used, "on" if jitter else "off"),
                 "primitives": scene.packed.desc.n_spheres + scene.packed.desc.n_boxes + scene.packed.desc.n_planes,
                 "lights": scene.packed.desc.n_lights, "bsp_nodes": scene.packed.desc.n_nodes,
                 "rays_per_frame": int(rays_per_frame), "partition": "8x8 tiles interleaved over %d rank(s)" % world,
-                "ingest": ingest_info},
+                "frame_state_device_bytes": ctx.frame_bytes(),
+                "voided_frames_in_timed_loop": 0, "ingest": ingest_info},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
+        if split:
+            line["render_gather_split"] = split
+        if extra:
+            line["extra_frames"] = extra
         print(json.dumps(line), flush=True)
     ctx.close()
     if world > 1:

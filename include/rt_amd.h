@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RT_AMD_ABI_VERSION 1
+#define RT_AMD_ABI_VERSION 2
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -153,6 +153,8 @@ typedef struct rt_stats {
     double ms_intersect, ms_shadow, ms_shade; /* per kernel family, summed over levels (RT_FLAG_PROFILE only) */
     double ms_gen, ms_resolve;   /* RT_FLAG_PROFILE only */
     int64_t launches_per_family; /* RT_FLAG_PROFILE only: number of k_intersect (= k_shadow = k_shade) launches */
+    double ms_beam_setup;        /* RT_FLAG_PROFILE only: HIP events around the k_beam_setup launches alone (the frame's dominant kernel) */
+    int64_t beam_setup_launches; /* RT_FLAG_PROFILE only */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;
@@ -199,6 +201,15 @@ int rt_render_device(rt_ctx *ctx, const rt_render_params *p, float *d_rgb_out, u
                      int32_t *d_ids_out, void *stream);
 /* Wait for the context's stream and fetch the counters of the last frame. */
 int rt_sync_stats(rt_ctx *ctx, rt_stats *stats);
+
+/* Frames voided by a queue overflow (RT_ERR_QUEUE_OVERFLOW) since the context was created or the counter was last reset,
+ * counted on the device at the end of every frame - also of frames whose counters nobody fetched with rt_sync_stats (a
+ * timing loop checks it ONCE after its last frame: a voided frame returns early and would be timed as a fast one).
+ * Synchronises the device. */
+int rt_voided_frames(rt_ctx *ctx, int reset, int64_t *count);
+
+/* Device bytes of the frame state (ray queues, hit and pair records, framebuffers) the context currently holds. */
+int64_t rt_frame_bytes(const rt_ctx *ctx);
 
 /*
  * rt_render_device for callers that cannot allocate.  No counterpart in the reference: it exists for code under HIP graph

@@ -2,7 +2,7 @@
 loading).  Kept field-for-field in the order of the header."""
 import ctypes as C
 
-RT_AMD_ABI_VERSION = 1
+RT_AMD_ABI_VERSION = 2
 RT_USE_SCENE_VALUE = -2147483648
 RT_SURF_BACKGROUND, RT_SURF_SPHERE, RT_SURF_BOX, RT_SURF_PLANE = 0, 1, 2, 3
 RT_FLAG_EXACT_TRAVERSAL = 1
@@ -54,6 +54,7 @@ class Stats(C.Structure):
         ("transmit_rays", C.c_int64), ("hits", C.c_int64), ("levels", C.c_int64), ("max_queue", C.c_int64),
         ("ms_total", C.c_double), ("ms_intersect", C.c_double), ("ms_shadow", C.c_double), ("ms_shade", C.c_double),
         ("ms_gen", C.c_double), ("ms_resolve", C.c_double), ("launches_per_family", C.c_int64),
+        ("ms_beam_setup", C.c_double), ("beam_setup_launches", C.c_int64),
     ]
 
     def as_dict(self):

@@ -1230,13 +1230,20 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, LevelParams lp, Ra
 // fbm: the background that the rays of levels 1.. add when they miss (k_intersect).  It is kept apart from fb because
 // the nearest-hit query of level L+1 runs beside the shading of level L: with one buffer the order of the float64
 // additions on a pixel would depend on the schedule.
-__global__ void __launch_bounds__(RT_BLOCK) k_resolve(const double *fb, const double *fb0, const double *fbm, uint64_t n_values, float *rgb, uint8_t *rgb8) {
+__global__ void __launch_bounds__(RT_BLOCK) k_resolve(const double *fb, const double *fb0, const double *fbm, uint64_t n_values, float *rgb, uint8_t *rgb8,
+                                                      const FrameCtl *ctl, uint32_t *voided) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && ctl->overflow) atomicAdd(voided, 1u);     // rt_voided_frames
     for (uint64_t k = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x; k < n_values; k += (uint64_t)gridDim.x * RT_BLOCK) {
         double v = (fb0[k] + fb[k]) + fbm[k];
         double c = v < 0 ? 0 : (v > 1 ? 1 : v);
         if (rgb) rgb[k] = (float)c;
         if (rgb8) rgb8[k] = isnan(c) ? (uint8_t)0 : (uint8_t)(c * 255);
     }
+}
+
+// end of a frame that writes no image: count it when a queue overflow voided it (rt_voided_frames)
+__global__ void k_frame_end(const FrameCtl *ctl, uint32_t *voided) {
+    if (threadIdx.x == 0 && ctl->overflow) atomicAdd(voided, 1u);
 }
 
 // mean of K clipped frames: acc (+)= clip(frame); the last frame divides and quantises like k_resolve
@@ -1388,8 +1395,37 @@ struct FrameState {
     FrameCtl *ctl = nullptr;
 };
 
+// RT_AMD_* environment switches (diagnostics / experiments), read ONCE in rt_create: a frame takes ~2 ms, a getenv per
+// launch decision is host time on its critical path
+struct EnvCfg {
+    long long walk_min = 3ll << 20;     // RT_AMD_WALK_MIN: k_shadow_walk takes a level's rays of overflowing pairs from this many on (1 = always, -1 = never)
+    int beam_early = -1;                // RT_AMD_BEAM_EARLY = 0 | 1 (default: by scene size)
+    bool box_kernels = false;           // RT_AMD_BOX_KERNELS: box-capable kernel templates even without boxes
+    bool no_prio = false, prio = false; // RT_AMD_NO_PRIO / RT_AMD_PRIO: wave priority of the deeper levels
+    bool no_pipeline = false;           // RT_AMD_NO_PIPELINE: deeper levels on one stream
+    bool debug = false;                 // RT_AMD_DEBUG: per-level diagnostics on stderr
+    bool exact = false;                 // RT_AMD_EXACT: batched queries through the reference-order walk
+    int ovl_main = 3, ovl_side = 1, ovl_main2 = 3;   // RT_AMD_OVL_*: workgroups per CU of the two sides of an overlapped frame
+    void read() {
+        if (const char *e = getenv("RT_AMD_WALK_MIN")) walk_min = atoll(e);
+        if (const char *e = getenv("RT_AMD_BEAM_EARLY")) beam_early = atoi(e) != 0;
+        box_kernels = getenv("RT_AMD_BOX_KERNELS") != nullptr;
+        no_prio = getenv("RT_AMD_NO_PRIO") != nullptr; prio = getenv("RT_AMD_PRIO") != nullptr;
+        no_pipeline = getenv("RT_AMD_NO_PIPELINE") != nullptr;
+        debug = getenv("RT_AMD_DEBUG") != nullptr;
+        exact = getenv("RT_AMD_EXACT") != nullptr;
+        if (const char *e = getenv("RT_AMD_OVL_MAIN")) ovl_main = atoi(e);
+        if (const char *e = getenv("RT_AMD_OVL_SIDE")) ovl_side = atoi(e);
+        if (const char *e = getenv("RT_AMD_OVL_MAIN2")) ovl_main2 = atoi(e);
+    }
+};
+
 struct rt_ctx : FrameState {
     int device = 0;
+    EnvCfg env;
+    uint32_t *d_voided = nullptr;           // frames voided by a queue overflow since the last rt_voided_frames(reset) (device counter)
+    std::vector<hipEvent_t> prof_bs;        // RT_FLAG_PROFILE: [start, end] of k_beam_setup per level
+    int prof_bs_levels = 0;
     hipStream_t stream = nullptr;
     std::string error;
     std::vector<void *> scene_allocs;
@@ -1597,6 +1633,9 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
     HIP_C(hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
     HIP_C(rt_event_create(&ctx->ev_fork, false));
     HIP_C(rt_event_create(&ctx->ev_join, false));
+    ctx->env.read();
+    HIP_C(rt_malloc(&ctx->d_voided, sizeof(uint32_t)));
+    HIP_C(hipMemset(ctx->d_voided, 0, sizeof(uint32_t)));
     HIP_C(rt_malloc(&ctx->ctl_own, sizeof(FrameCtl)));
     ctx->ctl = ctx->ctl_own;
     if (int rc = scratch_address(ctx, device, nullptr)) return bail(rc);      // the no-alloc entry point's buffer on this device, looked up once
@@ -1896,6 +1935,8 @@ extern "C" int rt_destroy(rt_ctx *ctx) {
     free_frame(ctx);
     for (void *p : ctx->scene_allocs) (void)hipFree(p);
     if (ctx->ctl_own) (void)hipFree(ctx->ctl_own);
+    if (ctx->d_voided) (void)hipFree(ctx->d_voided);
+    for (hipEvent_t e : ctx->prof_bs) (void)hipEventDestroy(e);
     if (ctx->acc) (void)hipFree(ctx->acc);
     if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -2109,7 +2150,13 @@ static int prof_prepare(rt_ctx *ctx, int levels) {
         HIP_TRY(ctx, rt_event_create(&e, true));
         ctx->prof_ev.push_back(e);
     }
+    while (ctx->prof_bs.size() < 2 * (size_t)levels) {
+        hipEvent_t e;
+        HIP_TRY(ctx, rt_event_create(&e, true));
+        ctx->prof_bs.push_back(e);
+    }
     ctx->prof_levels = levels;
+    ctx->prof_bs_levels = 0;
     return RT_OK;
 }
 #define PROF_MARK(idx) do { if (prof) HIP_TRY(ctx, hipEventRecord(ctx->prof_ev[(idx)], st)); } while (0)
@@ -2141,13 +2188,11 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
     {
         // k_shadow_walk pays when a level has millions of rays in overflowing pairs (1 M lattice: 17 M); with few of them
         // a second latency-bound kernel only adds its tail.  RT_AMD_WALK_MIN: 1 = always, -1 = never (diagnostic).
-        const char *e = getenv("RT_AMD_WALK_MIN");
-        const long long v = e ? atoll(e) : (3ll << 20);
+        const long long v = ctx->env.walk_min;
         lp.walk_min = v < 0 || v > 0xfffffffell ? 0xffffffffu : (uint32_t)v;
         // beams that cross many primitives before they leave the scene (large lattices under low lights): stop at the first
         // sphere that covers the light.  Costs ~7 % on scenes whose beams are short; chosen by size, RT_AMD_BEAM_EARLY=0|1 overrides
-        const char *b = getenv("RT_AMD_BEAM_EARLY");
-        lp.beam_early = b ? (atoi(b) != 0) : (ctx->S.n_prims >= 100000);
+        lp.beam_early = ctx->env.beam_early >= 0 ? ctx->env.beam_early : (ctx->S.n_prims >= 100000);
     }
     dim3 block(RT_BLOCK);
     const bool prof = (p->flags & RT_FLAG_PROFILE) != 0;
@@ -2163,9 +2208,9 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         lp.magic_s = (uint32_t)((0x100000000ull + (uint32_t)sh - 1) / (uint32_t)sh);
     }
     const bool overlap = fast && !prof && rec >= 1 && fb0 != ctx->fb && ctx->two_sets && !(p->flags & RT_FLAG_NO_OVERLAP) && ctx->n_cu >= 8;
-    static const int ovl_main = getenv("RT_AMD_OVL_MAIN") ? atoi(getenv("RT_AMD_OVL_MAIN")) : 3;   // workgroups per CU, level-0 side
-    static const int ovl_side = getenv("RT_AMD_OVL_SIDE") ? atoi(getenv("RT_AMD_OVL_SIDE")) : 1;   // deeper levels
-    static const int ovl_main2 = getenv("RT_AMD_OVL_MAIN2") ? atoi(getenv("RT_AMD_OVL_MAIN2")) : 3;  // level-0 kernels after the beam setup (side 3)
+    const int ovl_main = ctx->env.ovl_main;     // workgroups per CU, level-0 side
+    const int ovl_side = ctx->env.ovl_side;     // deeper levels
+    const int ovl_main2 = ctx->env.ovl_main2;   // level-0 kernels after the beam setup (side 3)
     // grid of a kernel with nb workgroups per CU at full occupancy: side 0 = sequential, 1 = level-0 side, 2 = deeper levels
     auto gsz = [&](int full, int nb, int side) {
         if (!overlap || side == 0) return full;
@@ -2182,11 +2227,13 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
             {
                 // the kernel template that fits the scene: long beams or not, boxes or spheres only
                 const dim3 gs(gsz(ctx->g_beam_setup, ctx->nb_beam_setup, side));
-                const bool boxes = ctx->n_boxes > 0 || getenv("RT_AMD_BOX_KERNELS") != nullptr;
+                const bool boxes = ctx->n_boxes > 0 || ctx->env.box_kernels;
+                if (prof) HIP_TRY(ctx, hipEventRecord(ctx->prof_bs[2 * level], s_));      // the frame's dominant kernel on its own (bench.py: roofline)
                 if (lp.beam_early && boxes) hipLaunchKernelGGL((k_beam_setup<true, true>), gs, block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
                 else if (lp.beam_early) hipLaunchKernelGGL((k_beam_setup<true, false>), gs, block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
                 else if (boxes) hipLaunchKernelGGL((k_beam_setup<false, true>), gs, block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
                 else hipLaunchKernelGGL((k_beam_setup<false, false>), gs, block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
+                if (prof) { HIP_TRY(ctx, hipEventRecord(ctx->prof_bs[2 * level + 1], s_)); ctx->prof_bs_levels = level + 1; }
             }
             hipLaunchKernelGGL(k_shadow_beam, dim3(gsz(ctx->g_beam, ctx->nb_beam, side == 1 ? 3 : side)), block, 0, s_, ctx->S, lp, hb, bb, ctx->ctl);
             // k_shadow_walk only where the last frame of this shape had work for it (rt_ctx::seen_walk); without the launch
@@ -2253,11 +2300,11 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                            ctx->beam.litbits, ctx->beam.pair_slot, ctx->beam.queue_n);
         // deeper levels (stream2): few, long rays - their waves ask for issue priority over the level-0 waves
         // (in frames of many million pixels the level-0 side is the long one and the priority only slows it down)
-        lp.prio = getenv("RT_AMD_NO_PRIO") ? 0 : (getenv("RT_AMD_PRIO") || ctx->fb_slots_frame <= (4u << 20) ? 1 : 0);
+        lp.prio = ctx->env.no_prio ? 0 : (ctx->env.prio || ctx->fb_slots_frame <= (4u << 20) ? 1 : 0);
         lp.level = 0; lp.last_level = 0;
         hipLaunchKernelGGL(k_shade<RT_SHADE_SPAWN>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s2_, ctx->S, lp, ctx->q[0], ctx->q[1], ctx->hb, ctx->ctl, ctx->fb,
                            ctx->beam.litbits, ctx->beam.pair_slot, ctx->beam.queue_n);
-        const bool no_pipe = getenv("RT_AMD_NO_PIPELINE") != nullptr;
+        const bool no_pipe = ctx->env.no_pipeline;
         if (ctx->three_sets && rec >= 2 && !no_pipe) {
             hipStream_t s3_ = ctx->stream3;
             while ((int)ctx->ev_hit.size() <= rec) {
@@ -2357,7 +2404,8 @@ static int enqueue_frame(rt_ctx *ctx, const rt_render_params *p, const TileGeom 
         if (int rc = enqueue_levels(ctx, p, sh, rec, d_ids, st, ctx->fb0, prof ? nullptr : &gp, ctx->fbm)) return rc;
     }
     PROF_MARK(2 + 6 * (rec + 1));
-    if (d_rgb || d_rgb8) hipLaunchKernelGGL(k_resolve, grid, block, 0, st, ctx->fb, ctx->fb0, ctx->fbm, g.out_slots * 3, d_rgb, d_rgb8);
+    if (d_rgb || d_rgb8) hipLaunchKernelGGL(k_resolve, grid, block, 0, st, ctx->fb, ctx->fb0, ctx->fbm, g.out_slots * 3, d_rgb, d_rgb8, ctx->ctl, ctx->d_voided);
+    else hipLaunchKernelGGL(k_frame_end, dim3(1), dim3(64), 0, st, ctx->ctl, ctx->d_voided);
     PROF_MARK(3 + 6 * (rec + 1));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctl, ctx->ctl, sizeof(FrameCtl), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
@@ -2470,9 +2518,14 @@ extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
             }
             stats->ms_resolve = span(2 + 6 * ctx->prof_levels);
             stats->launches_per_family = ctx->prof_levels;
+            for (int l = 0; l < ctx->prof_bs_levels; ++l) {
+                float t = 0;
+                if (hipEventElapsedTime(&t, ctx->prof_bs[2 * l], ctx->prof_bs[2 * l + 1]) == hipSuccess) stats->ms_beam_setup += t;
+            }
+            stats->beam_setup_launches = ctx->prof_bs_levels;
         }
     }
-    if (getenv("RT_AMD_DEBUG") && ctx->beam.rec && c.n_hits[0] > 0) {
+    if (ctx->env.debug && ctx->beam.rec && c.n_hits[0] > 0) {
         // beam path diagnostics: per level, pairs / pairs that needed the per-ray filter / rays that needed float64
         for (int l = 0; l <= ctx->last_rec && l < RT_MAX_LEVELS; ++l)
             fprintf(stderr, "[rt_amd] level %d: %llu pairs, %u listed, %u rays of overflowing pairs, %u rays queued by the filters\n", l,
@@ -2510,6 +2563,19 @@ extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
         else ctx->growth *= 2.0;
         return fail(ctx, RT_ERR_QUEUE_OVERFLOW, "secondary-ray queue overflow; queue growth factor doubled, render again");
     }
+    return RT_OK;
+}
+
+extern "C" int64_t rt_frame_bytes(const rt_ctx *ctx) { return ctx ? (int64_t)ctx->frame_bytes : -1; }
+
+extern "C" int rt_voided_frames(rt_ctx *ctx, int reset, int64_t *count) {
+    if (!ctx || !count) return RT_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    uint32_t v = 0;
+    HIP_TRY(ctx, hipMemcpy(&v, ctx->d_voided, sizeof(v), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(ctx, hipMemset(ctx->d_voided, 0, sizeof(v)));
+    *count = (int64_t)v;
     return RT_OK;
 }
 
@@ -2645,9 +2711,10 @@ extern "C" int rt_trace(rt_ctx *ctx, const rt_render_params *p, const double *or
             rc = enqueue_levels(ctx, &pp, sh, rec, nullptr, st, ctx->fb, nullptr, ctx->fb);   // one framebuffer: rgb_out is its raw float64 content
             if (rc != RT_OK) break;
         }
+        hipLaunchKernelGGL(k_frame_end, dim3(1), dim3(64), 0, st, ctx->ctl, ctx->d_voided);
         TRY_T(hipMemcpyAsync(ctx->h_ctl, ctx->ctl, sizeof(FrameCtl), hipMemcpyDeviceToHost, st));
         TRY_T(hipEventRecord(ctx->ev1, st));
-        ctx->last = *p; ctx->last_sh = sh; ctx->last_rec = rec; ctx->last_slots = (uint64_t)n; ctx->last_gen = false;
+        ctx->last = *p; ctx->last_sh = sh; ctx->last_rec = rec; ctx->last_slots = (uint64_t)n; ctx->last_gen = false; ctx->last_noalloc = false;
         rc = rt_sync_stats(ctx, stats);
         if (rc != RT_ERR_QUEUE_OVERFLOW) break;
     }
@@ -2679,7 +2746,7 @@ extern "C" int rt_intersect(rt_ctx *ctx, const double *origins, const double *di
     TRY_I(rt_malloc(&d_i, (size_t)n * sizeof(int64_t)));
     TRY_I(hipMemcpy(d_o, origins, vb, hipMemcpyHostToDevice));
     TRY_I(hipMemcpy(d_d, directions, vb, hipMemcpyHostToDevice));
-    if (ctx->F.ok && !getenv("RT_AMD_EXACT"))
+    if (ctx->F.ok && !ctx->env.exact)
         hipLaunchKernelGGL(k_intersect_only<true>, dim3(ctx->grid), dim3(RT_BLOCK), ctx->lds_bytes, ctx->stream, ctx->S, ctx->F, d_o, d_d, (uint64_t)n, d_p, d_i);
     else
         hipLaunchKernelGGL(k_intersect_only<false>, dim3(ctx->grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->S, ctx->F, d_o, d_d, (uint64_t)n, d_p, d_i);
@@ -2711,7 +2778,7 @@ extern "C" int rt_visibility(rt_ctx *ctx, const double *origins, const double *d
     TRY_V(hipMemcpy(d_v, origins, vb, hipMemcpyHostToDevice));
     TRY_V(hipMemcpy(d_v + vn, directions, vb, hipMemcpyHostToDevice));
     TRY_V(hipMemcpy(d_v + 2 * vn, targets, vb, hipMemcpyHostToDevice));
-    if (ctx->F.ok && !getenv("RT_AMD_EXACT"))
+    if (ctx->F.ok && !ctx->env.exact)
         hipLaunchKernelGGL(k_visibility<true>, dim3(ctx->grid), dim3(RT_BLOCK), ctx->lds_bytes, ctx->stream, ctx->S, ctx->F, d_v, d_v + vn, d_v + 2 * vn, (uint64_t)n, d_l);
     else
         hipLaunchKernelGGL(k_visibility<false>, dim3(ctx->grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->S, ctx->F, d_v, d_v + vn, d_v + 2 * vn, (uint64_t)n, d_l);

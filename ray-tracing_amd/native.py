@@ -12,12 +12,12 @@ import numpy as np
 from . import abi
 
 _PKG = os.path.dirname(os.path.abspath(abi.__file__))
-LIB_PATH = os.path.join(_PKG, "csrc", "librt_amd.so")
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_PKG, "csrc", "librt_amd.so")    # RT_AMD_LIB: A/B runs of two builds (tools/)
 _LIB = None
 
 EXPORTS = ("rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_tile_pixels", "rt_tile_layout",
            "rt_render", "rt_render_mean", "rt_render_device", "rt_render_device_noalloc", "rt_noalloc_scratch_bytes",
-           "rt_debug_alloc_calls", "rt_sync_stats", "rt_trace", "rt_intersect", "rt_visibility",
+           "rt_debug_alloc_calls", "rt_sync_stats", "rt_voided_frames", "rt_frame_bytes", "rt_trace", "rt_intersect", "rt_visibility",
            "rt_deinterleave_u8",
            "rt_initial_rays", "rt_unit_prim_intersect", "rt_unit_prim_normals", "rt_unit_slab_mask",
            "rt_bsp_build", "rt_bsp_stats_get", "rt_bsp_fetch", "rt_bsp_destroy", "rt_bsp_last_error",
@@ -54,6 +54,9 @@ def lib():
         L.rt_noalloc_scratch_bytes.restype = C.c_int64
         L.rt_debug_alloc_calls.restype = C.c_int64
         L.rt_sync_stats.argtypes = [C.c_void_p, C.POINTER(abi.Stats)]
+        L.rt_frame_bytes.restype = C.c_int64
+        L.rt_frame_bytes.argtypes = [C.c_void_p]
+        L.rt_voided_frames.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
         L.rt_trace.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_void_p, C.POINTER(abi.Stats)]
         L.rt_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
@@ -181,6 +184,15 @@ class Context:
         st = abi.Stats()
         _check(lib().rt_sync_stats(self._h, C.byref(st)), self._h)
         return st.as_dict()
+
+    def frame_bytes(self):
+        return int(lib().rt_frame_bytes(self._h))
+
+    def voided_frames(self, reset=False):
+        """Frames voided by a queue overflow since creation / the last reset (device counter; synchronises)."""
+        n = C.c_int64()
+        _check(lib().rt_voided_frames(self._h, 1 if reset else 0, C.byref(n)), self._h)
+        return int(n.value)
 
     def deinterleave_u8(self, params, d_packed, stride_bytes, d_image, stream=0):
         _check(lib().rt_deinterleave_u8(self._h, C.byref(params), C.c_void_p(d_packed), int(stride_bytes),
