@@ -615,6 +615,10 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                 if (bo.occ_all) whole = RT_PAIR_UNLIT;
                 else if (bo.nu == 0 && n_eval == 0) whole = (n_atp + (bo.atp_all ? 1u : 0u)) > 0 ? RT_PAIR_LIT : RT_PAIR_UNLIT;
             }
+            // Samples outside the per-ray filter's range (P a million units from the light: a reflection that left the scene and
+            // met the ground plane far out): nothing the beam found may be dropped - a pair that is "occluded as a whole" would
+            // otherwise be listed WITHOUT the occluder.  Every ray of such a pair is decided in float64.
+            if (!range_ok) { bo.overflow = true; delicate = true; }
             if (whole) bb.pair_slot[(uint64_t)ml * lp.cap + h] = whole;
             else if (bo.overflow) {
                 // too many primitives along the beam (or a delicate basis): k_shadow_walk sends each ray through the
