@@ -1632,7 +1632,10 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
     HIP_C(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIP_C(rt_event_create(&ctx->ev0, true));
     HIP_C(rt_event_create(&ctx->ev1, true));
-    // (a high-priority stream here hung the GPU under the persistent level-0 kernels; wave priority is set in the kernels instead)
+    // Plain streams, all of one priority.  (Round 1 tried a high-priority stream for the deeper levels; a run with it hung and no
+    // log was kept.  DESIGN.md section 8, "The recorded hang", goes through what the schedule itself can and cannot do - it holds
+    // no wait that a kernel of another stream must resolve - and why the experiment is not repeated; s_setprio in the kernels
+    // gives the same bias without a second queue priority.)
     HIP_C(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
     HIP_C(hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
     HIP_C(rt_event_create(&ctx->ev_fork, false));
@@ -2211,7 +2214,13 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         lp.magic_s2 = (uint32_t)((0x100000000ull + s2 - 1) / s2);
         lp.magic_s = (uint32_t)((0x100000000ull + (uint32_t)sh - 1) / (uint32_t)sh);
     }
-    const bool overlap = fast && !prof && rec >= 1 && fb0 != ctx->fb && ctx->two_sets && !(p->flags & RT_FLAG_NO_OVERLAP) && ctx->n_cu >= 8;
+    // Both sides of an overlapped frame are fixed grids of resident workgroups: the level-0 side may hold at most ovl_main
+    // (ovl_main2) of a CU's 4 workgroup slots (amdgpu_waves_per_eu(4, 4), 256 threads each), the deeper levels ovl_side - together
+    // never more than the slots there are, so that neither side ever waits for the other to retire (no kernel here spins on
+    // another one's results, but a side that cannot get a slot runs after the other instead of beside it).
+    const bool slots_ok = ctx->env.ovl_main >= 1 && ctx->env.ovl_side >= 1 && ctx->env.ovl_main + ctx->env.ovl_side <= 4 &&
+                          ctx->env.ovl_main2 + ctx->env.ovl_side <= 4;
+    const bool overlap = fast && !prof && rec >= 1 && fb0 != ctx->fb && ctx->two_sets && !(p->flags & RT_FLAG_NO_OVERLAP) && ctx->n_cu >= 8 && slots_ok;
     const int ovl_main = ctx->env.ovl_main;     // workgroups per CU, level-0 side
     const int ovl_side = ctx->env.ovl_side;     // deeper levels
     const int ovl_main2 = ctx->env.ovl_main2;   // level-0 kernels after the beam setup (side 3)

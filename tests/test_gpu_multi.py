@@ -52,3 +52,23 @@ def test_ranks_gathered_and_deinterleaved_on_the_device_equal_the_whole_frame(be
         from ray_tracing_amd.render import deinterleave_host
         host = deinterleave_host(list(packed.cpu().numpy()), w, h, world, tile_w=tile, tile_h=tile)
         assert np.array_equal(host.reshape(-1), whole.cpu().numpy())
+
+
+def test_overlapped_schedule_at_the_largest_and_smallest_frames(bench_ctx):
+    """The three-stream schedule of a frame (level 0's soft shadows | nearest hits of levels 1.. | their shading) against
+    the levels in sequence, at 3840x2160 and at a single tile, alternating (events and buffer sets are reused from frame to
+    frame): same image, same counters."""
+    ctx = bench_ctx
+    for (w, h) in ((3840, 2160), (8, 8), (3840, 2160), (1, 1)):
+        kw = dict(sh_rays=5, rec_max=5, jitter=True, seed=31)
+        n = w * h
+        a = torch.zeros(n * 3, dtype=torch.float32, device="cuda:0")
+        b = torch.zeros(n * 3, dtype=torch.float32, device="cuda:0")
+        ctx.render_device(abi.render_params(w, h, **kw), d_rgb=a.data_ptr())
+        sa = ctx.sync_stats()
+        ctx.render_device(abi.render_params(w, h, flags=abi.RT_FLAG_NO_OVERLAP, **kw), d_rgb=b.data_ptr())
+        sb = ctx.sync_stats()
+        assert torch.equal(a, b), (w, h)
+        for key in ("rays", "hits", "reflect_rays", "levels"):
+            assert sa[key] == sb[key], key
+    assert ctx.voided_frames() == 0

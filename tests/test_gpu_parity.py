@@ -376,7 +376,8 @@ def test_beam_path_frame_matches_oracle_on_stress_scene(oracle):
     assert out["stats"]["shadow_rays"] == ref["counters"]["shadow_rays"]
 
 
-@pytest.mark.parametrize("tag,w,h,sh,rec", [("synth400", 320, 180, 5, 5), ("pool", 320, 180, 3, 10), ("small", 160, 100, 2, 4)])
+@pytest.mark.parametrize("tag,w,h,sh,rec", [("synth400", 320, 180, 5, 5), ("pool", 320, 180, 3, 10), ("small", 160, 100, 2, 4),
+                                            ("small", 1, 1, 3, 4), ("pool", 8, 8, 5, 10), ("original", 3, 2, 3, 10)])
 def test_overlapped_levels_equal_sequential_levels(gpu_ctx, tag, w, h, sh, rec):
     """The default schedule runs levels 1.. beside the soft shadows of level 0 (second stream, second buffer set);
     RT_FLAG_NO_OVERLAP runs the levels one after the other.  Same frame, same counters, several frames in a row."""
