@@ -258,6 +258,18 @@ int rt_intersect(rt_ctx *ctx, const double *origins, const double *directions, i
 int rt_visibility(rt_ctx *ctx, const double *origins, const double *directions, const double *targets, int64_t n,
                   uint8_t *lit_out);
 
+/*
+ * The two batched queries on DEVICE buffers (PyTorch / HIP callers): same kernels, same results as
+ * rt_intersect / rt_visibility, but nothing crosses PCIe and nothing is allocated - the kernel is only enqueued on
+ * `stream` (a hipStream_t, NULL = the context's own stream) and nothing is synchronised.  Buffers: C-contiguous float64
+ * [n*3] on ctx's device (ids int64 [n], lit uint8 [n]).  Replaces BSPNode.intersect_vectorize (BSPNode.py:201-210) and the
+ * lit test of Light.compute_shadows (Light.py:214-221) for callers whose rays already live in HBM.
+ */
+int rt_intersect_device(rt_ctx *ctx, const double *d_origins, const double *d_directions, int64_t n, double *d_points_out,
+                        int64_t *d_ids_out, void *stream);
+int rt_visibility_device(rt_ctx *ctx, const double *d_origins, const double *d_directions, const double *d_targets, int64_t n,
+                         uint8_t *d_lit_out, void *stream);
+
 /* Rank-0 side of the multi-GPU gather: scatter `world` packed per-rank tile
  * buffers (device memory, rank r at d_packed + r*stride_bytes) into a row-major
  * W*H*3 uint8 image on the device. */

@@ -1427,6 +1427,8 @@ struct EnvCfg {
 struct rt_ctx : FrameState {
     int device = 0;
     EnvCfg env;
+    unsigned char *stage = nullptr;         // grow-only device staging for the blocking host-buffer entry points (no hipMalloc per call)
+    size_t stage_bytes = 0;
     uint32_t *d_voided = nullptr;           // frames voided by a queue overflow since the last rt_voided_frames(reset) (device counter)
     std::vector<hipEvent_t> prof_bs;        // RT_FLAG_PROFILE: [start, end] of k_beam_setup per level
     int prof_bs_levels = 0;
@@ -1943,6 +1945,7 @@ extern "C" int rt_destroy(rt_ctx *ctx) {
     for (void *p : ctx->scene_allocs) (void)hipFree(p);
     if (ctx->ctl_own) (void)hipFree(ctx->ctl_own);
     if (ctx->d_voided) (void)hipFree(ctx->d_voided);
+    if (ctx->stage) (void)hipFree(ctx->stage);
     for (hipEvent_t e : ctx->prof_bs) (void)hipEventDestroy(e);
     if (ctx->acc) (void)hipFree(ctx->acc);
     if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
@@ -2579,6 +2582,29 @@ extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
     return RT_OK;
 }
 
+// Device staging of the host-buffer entry points: one grow-only allocation per context, carved per call (these calls block,
+// so one call's staging is free again when the next one starts).
+struct Stage {
+    rt_ctx *ctx;
+    size_t used = 0;
+    int reserve(size_t bytes) {
+        if (ctx->stage_bytes >= bytes) return RT_OK;
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        if (ctx->stage) (void)hipFree(ctx->stage);
+        ctx->stage = nullptr; ctx->stage_bytes = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        HIP_TRY(ctx, rt_malloc(&ctx->stage, want));
+        ctx->stage_bytes = want;
+        return RT_OK;
+    }
+    template <typename T> T *take(size_t n) {
+        T *p = (T *)(ctx->stage + used);
+        used += (n * sizeof(T) + 255) & ~(size_t)255;
+        return p;
+    }
+    static size_t pad(size_t b) { return (b + 255) & ~(size_t)255; }
+};
+
 extern "C" int64_t rt_frame_bytes(const rt_ctx *ctx) { return ctx ? (int64_t)ctx->frame_bytes : -1; }
 
 extern "C" int rt_voided_frames(rt_ctx *ctx, int reset, int64_t *count) {
@@ -2599,32 +2625,25 @@ extern "C" int rt_render(rt_ctx *ctx, const rt_render_params *p, float *rgb_out,
     std::string why;
     if (int rc = tile_geom(p, g, why)) return fail(ctx, rc, why);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    float *d_rgb = nullptr;
-    uint8_t *d_rgb8 = nullptr;
-    int32_t *d_ids = nullptr;
+    Stage sg{ctx};
+    const bool want8 = rgb8_out || !rgb_out;
+    if (int rc = sg.reserve((rgb_out ? Stage::pad(g.out_slots * 3 * sizeof(float)) : 0) + (want8 ? Stage::pad(g.out_slots * 3) : 0) +
+                            (ids_out ? Stage::pad(g.out_slots * sizeof(int32_t)) : 0))) return rc;
+    float *d_rgb = rgb_out ? sg.take<float>(g.out_slots * 3) : nullptr;
+    uint8_t *d_rgb8 = want8 ? sg.take<uint8_t>(g.out_slots * 3) : nullptr;
+    int32_t *d_ids = ids_out ? sg.take<int32_t>(g.out_slots) : nullptr;
     int rc = RT_OK;
-    auto cleanup = [&]() {
-        if (d_rgb) (void)hipFree(d_rgb);
-        if (d_rgb8) (void)hipFree(d_rgb8);
-        if (d_ids) (void)hipFree(d_ids);
-    };
-#define TRY_R(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
-    if (rgb_out) TRY_R(rt_malloc(&d_rgb, g.out_slots * 3 * sizeof(float)));
-    if (rgb8_out || !rgb_out) TRY_R(rt_malloc(&d_rgb8, g.out_slots * 3));
-    if (ids_out) TRY_R(rt_malloc(&d_ids, g.out_slots * sizeof(int32_t)));
-    for (int attempt = 0; attempt < 10; ++attempt) {
+    for (int attempt = 0; attempt < 10; ++attempt) {      // a frame voided by RT_ERR_QUEUE_OVERFLOW is rendered again with the enlarged queues
         rc = rt_render_device(ctx, p, d_rgb, d_rgb8, d_ids, nullptr);
         if (rc != RT_OK) break;
         rc = rt_sync_stats(ctx, stats);
         if (rc != RT_ERR_QUEUE_OVERFLOW) break;
     }
     if (rc == RT_OK) {
-        if (rgb_out) TRY_R(hipMemcpy(rgb_out, d_rgb, g.out_slots * 3 * sizeof(float), hipMemcpyDeviceToHost));
-        if (rgb8_out) TRY_R(hipMemcpy(rgb8_out, d_rgb8, g.out_slots * 3, hipMemcpyDeviceToHost));
-        if (ids_out) TRY_R(hipMemcpy(ids_out, d_ids, g.out_slots * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (rgb_out) HIP_TRY(ctx, hipMemcpy(rgb_out, d_rgb, g.out_slots * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        if (rgb8_out) HIP_TRY(ctx, hipMemcpy(rgb8_out, d_rgb8, g.out_slots * 3, hipMemcpyDeviceToHost));
+        if (ids_out) HIP_TRY(ctx, hipMemcpy(ids_out, d_ids, g.out_slots * sizeof(int32_t), hipMemcpyDeviceToHost));
     }
-#undef TRY_R
-    cleanup();
     return rc;
 }
 
@@ -2643,16 +2662,13 @@ extern "C" int rt_render_mean(rt_ctx *ctx, const rt_render_params *p, int32_t fr
         HIP_TRY(ctx, rt_malloc(&ctx->acc, g.out_slots * 3 * sizeof(double)));
         ctx->acc_slots = g.out_slots;
     }
-    float *d_rgb = nullptr;
-    uint8_t *d_rgb8 = nullptr;
+    Stage sg{ctx};
+    if (int rc0 = sg.reserve((rgb_out ? Stage::pad(g.out_slots * 3 * sizeof(float)) : 0) + (rgb8_out ? Stage::pad(g.out_slots * 3) : 0))) return rc0;
+    float *d_rgb = rgb_out ? sg.take<float>(g.out_slots * 3) : nullptr;
+    uint8_t *d_rgb8 = rgb8_out ? sg.take<uint8_t>(g.out_slots * 3) : nullptr;
     int rc = RT_OK;
-    auto cleanup = [&]() {
-        if (d_rgb) (void)hipFree(d_rgb);
-        if (d_rgb8) (void)hipFree(d_rgb8);
-    };
+    auto cleanup = [&]() {};
 #define TRY_M(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
-    if (rgb_out) TRY_M(rt_malloc(&d_rgb, g.out_slots * 3 * sizeof(float)));
-    if (rgb8_out) TRY_M(rt_malloc(&d_rgb8, g.out_slots * 3));
     rt_stats sum;
     memset(&sum, 0, sizeof(sum));
     for (int32_t k = 0; k < frames && rc == RT_OK; ++k) {
@@ -2696,15 +2712,12 @@ extern "C" int rt_trace(rt_ctx *ctx, const rt_render_params *p, const double *or
     if (int rc = resolve_settings(ctx, p, sh, rec)) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    double *d_o = nullptr, *d_d = nullptr;
     int rc = RT_OK;
-    auto cleanup = [&]() {
-        if (d_o) (void)hipFree(d_o);
-        if (d_d) (void)hipFree(d_d);
-    };
+    auto cleanup = [&]() {};
 #define TRY_T(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
-    TRY_T(rt_malloc(&d_o, (size_t)n * 3 * sizeof(double)));
-    TRY_T(rt_malloc(&d_d, (size_t)n * 3 * sizeof(double)));
+    Stage sg{ctx};
+    if (int rc0 = sg.reserve(2 * Stage::pad((size_t)n * 3 * sizeof(double)))) return rc0;
+    double *d_o = sg.take<double>((size_t)n * 3), *d_d = sg.take<double>((size_t)n * 3);
     TRY_T(hipMemcpy(d_o, origins, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice));
     TRY_T(hipMemcpy(d_d, directions, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice));
     for (int attempt = 0; attempt < 10; ++attempt) {
@@ -2737,38 +2750,55 @@ extern "C" int rt_trace(rt_ctx *ctx, const rt_render_params *p, const double *or
     return rc;
 }
 
+// BSPNode.intersect_vectorize on device buffers: only enqueued on `stream` (NULL = the context's), nothing is synchronised
+extern "C" int rt_intersect_device(rt_ctx *ctx, const double *d_origins, const double *d_directions, int64_t n, double *d_points_out,
+                                   int64_t *d_ids_out, void *stream) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (!d_origins || !d_directions || !d_points_out || !d_ids_out || n < 0) return fail(ctx, RT_ERR_INVALID_ARG, "NULL argument or negative n");
+    if (n == 0) return RT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if (ctx->F.ok && !ctx->env.exact)
+        hipLaunchKernelGGL(k_intersect_only<true>, dim3(ctx->grid), dim3(RT_BLOCK), ctx->lds_bytes, st, ctx->S, ctx->F, d_origins, d_directions, (uint64_t)n, d_points_out, d_ids_out);
+    else
+        hipLaunchKernelGGL(k_intersect_only<false>, dim3(ctx->grid), dim3(RT_BLOCK), 0, st, ctx->S, ctx->F, d_origins, d_directions, (uint64_t)n, d_points_out, d_ids_out);
+    HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
+
 extern "C" int rt_intersect(rt_ctx *ctx, const double *origins, const double *directions, int64_t n, double *points_out,
                             int64_t *ids_out) {
     if (!ctx) return RT_ERR_INVALID_ARG;
     if (!origins || !directions || !points_out || !ids_out || n < 0) return fail(ctx, RT_ERR_INVALID_ARG, "NULL argument or negative n");
     if (n == 0) return RT_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    double *d_o = nullptr, *d_d = nullptr, *d_p = nullptr;
-    int64_t *d_i = nullptr;
-    auto cleanup = [&]() {
-        if (d_o) (void)hipFree(d_o);
-        if (d_d) (void)hipFree(d_d);
-        if (d_p) (void)hipFree(d_p);
-        if (d_i) (void)hipFree(d_i);
-    };
-#define TRY_I(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
-    size_t vb = (size_t)n * 3 * sizeof(double);
-    TRY_I(rt_malloc(&d_o, vb));
-    TRY_I(rt_malloc(&d_d, vb));
-    TRY_I(rt_malloc(&d_p, vb));
-    TRY_I(rt_malloc(&d_i, (size_t)n * sizeof(int64_t)));
-    TRY_I(hipMemcpy(d_o, origins, vb, hipMemcpyHostToDevice));
-    TRY_I(hipMemcpy(d_d, directions, vb, hipMemcpyHostToDevice));
+    const size_t vb = (size_t)n * 3 * sizeof(double);
+    Stage sg{ctx};
+    if (int rc = sg.reserve(3 * Stage::pad(vb) + Stage::pad((size_t)n * sizeof(int64_t)))) return rc;
+    double *d_o = sg.take<double>((size_t)n * 3), *d_d = sg.take<double>((size_t)n * 3), *d_p = sg.take<double>((size_t)n * 3);
+    int64_t *d_i = sg.take<int64_t>((size_t)n);
+    HIP_TRY(ctx, hipMemcpyAsync(d_o, origins, vb, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_d, directions, vb, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = rt_intersect_device(ctx, d_o, d_d, n, d_p, d_i, ctx->stream)) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(points_out, d_p, vb, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ids_out, d_i, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+// the any-hit query on device buffers (see rt_visibility): only enqueued on `stream`
+extern "C" int rt_visibility_device(rt_ctx *ctx, const double *d_origins, const double *d_directions, const double *d_targets,
+                                    int64_t n, uint8_t *d_lit_out, void *stream) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (!d_origins || !d_directions || !d_targets || !d_lit_out || n < 0) return fail(ctx, RT_ERR_INVALID_ARG, "NULL argument or negative n");
+    if (n == 0) return RT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     if (ctx->F.ok && !ctx->env.exact)
-        hipLaunchKernelGGL(k_intersect_only<true>, dim3(ctx->grid), dim3(RT_BLOCK), ctx->lds_bytes, ctx->stream, ctx->S, ctx->F, d_o, d_d, (uint64_t)n, d_p, d_i);
+        hipLaunchKernelGGL(k_visibility<true>, dim3(ctx->grid), dim3(RT_BLOCK), ctx->lds_bytes, st, ctx->S, ctx->F, d_origins, d_directions, d_targets, (uint64_t)n, d_lit_out);
     else
-        hipLaunchKernelGGL(k_intersect_only<false>, dim3(ctx->grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->S, ctx->F, d_o, d_d, (uint64_t)n, d_p, d_i);
-    TRY_I(hipGetLastError());
-    TRY_I(hipStreamSynchronize(ctx->stream));
-    TRY_I(hipMemcpy(points_out, d_p, vb, hipMemcpyDeviceToHost));
-    TRY_I(hipMemcpy(ids_out, d_i, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost));
-#undef TRY_I
-    cleanup();
+        hipLaunchKernelGGL(k_visibility<false>, dim3(ctx->grid), dim3(RT_BLOCK), 0, st, ctx->S, ctx->F, d_origins, d_directions, d_targets, (uint64_t)n, d_lit_out);
+    HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
 }
 
@@ -2778,28 +2808,17 @@ extern "C" int rt_visibility(rt_ctx *ctx, const double *origins, const double *d
     if (!origins || !directions || !targets || !lit_out || n < 0) return fail(ctx, RT_ERR_INVALID_ARG, "NULL argument or negative n");
     if (n == 0) return RT_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    double *d_v = nullptr;           // origins | directions | targets
-    uint8_t *d_l = nullptr;
-    auto cleanup = [&]() {
-        if (d_v) (void)hipFree(d_v);
-        if (d_l) (void)hipFree(d_l);
-    };
-#define TRY_V(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
     const size_t vn = (size_t)n * 3, vb = vn * sizeof(double);
-    TRY_V(rt_malloc(&d_v, 3 * vb));
-    TRY_V(rt_malloc(&d_l, (size_t)n));
-    TRY_V(hipMemcpy(d_v, origins, vb, hipMemcpyHostToDevice));
-    TRY_V(hipMemcpy(d_v + vn, directions, vb, hipMemcpyHostToDevice));
-    TRY_V(hipMemcpy(d_v + 2 * vn, targets, vb, hipMemcpyHostToDevice));
-    if (ctx->F.ok && !ctx->env.exact)
-        hipLaunchKernelGGL(k_visibility<true>, dim3(ctx->grid), dim3(RT_BLOCK), ctx->lds_bytes, ctx->stream, ctx->S, ctx->F, d_v, d_v + vn, d_v + 2 * vn, (uint64_t)n, d_l);
-    else
-        hipLaunchKernelGGL(k_visibility<false>, dim3(ctx->grid), dim3(RT_BLOCK), 0, ctx->stream, ctx->S, ctx->F, d_v, d_v + vn, d_v + 2 * vn, (uint64_t)n, d_l);
-    TRY_V(hipGetLastError());
-    TRY_V(hipStreamSynchronize(ctx->stream));
-    TRY_V(hipMemcpy(lit_out, d_l, (size_t)n, hipMemcpyDeviceToHost));
-#undef TRY_V
-    cleanup();
+    Stage sg{ctx};
+    if (int rc = sg.reserve(3 * Stage::pad(vb) + Stage::pad((size_t)n))) return rc;
+    double *d_o = sg.take<double>(vn), *d_d = sg.take<double>(vn), *d_t = sg.take<double>(vn);
+    uint8_t *d_l = sg.take<uint8_t>((size_t)n);
+    HIP_TRY(ctx, hipMemcpyAsync(d_o, origins, vb, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_d, directions, vb, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_t, targets, vb, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = rt_visibility_device(ctx, d_o, d_d, d_t, n, d_l, ctx->stream)) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(lit_out, d_l, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
 

@@ -17,7 +17,7 @@ _LIB = None
 
 EXPORTS = ("rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_tile_pixels", "rt_tile_layout",
            "rt_render", "rt_render_mean", "rt_render_device", "rt_render_device_noalloc", "rt_noalloc_scratch_bytes",
-           "rt_debug_alloc_calls", "rt_sync_stats", "rt_voided_frames", "rt_frame_bytes", "rt_trace", "rt_intersect", "rt_visibility",
+           "rt_debug_alloc_calls", "rt_sync_stats", "rt_voided_frames", "rt_frame_bytes", "rt_trace", "rt_intersect", "rt_visibility", "rt_intersect_device", "rt_visibility_device",
            "rt_deinterleave_u8",
            "rt_initial_rays", "rt_unit_prim_intersect", "rt_unit_prim_normals", "rt_unit_slab_mask",
            "rt_bsp_build", "rt_bsp_stats_get", "rt_bsp_fetch", "rt_bsp_destroy", "rt_bsp_last_error",
@@ -61,6 +61,8 @@ def lib():
                                C.c_void_p, C.POINTER(abi.Stats)]
         L.rt_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.rt_visibility.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.rt_intersect_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rt_visibility_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.rt_deinterleave_u8.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_int64, C.c_void_p,
                                          C.c_void_p]
         L.rt_initial_rays.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -231,6 +233,16 @@ class Context:
         _check(lib().rt_visibility(self._h, o.ctypes.data, d.ctypes.data, t.ctypes.data, o.shape[0],
                                    lit.ctypes.data), self._h)
         return lit.astype(bool)
+
+    def intersect_device(self, d_origins, d_directions, n, d_points, d_ids, stream=0):
+        """rt_intersect_device: raw device pointers (ints), float64 [n*3] in / out, int64 [n] ids; enqueued only."""
+        _check(lib().rt_intersect_device(self._h, C.c_void_p(d_origins), C.c_void_p(d_directions), int(n), C.c_void_p(d_points),
+                                         C.c_void_p(d_ids), C.c_void_p(stream or None)), self._h)
+
+    def visibility_device(self, d_origins, d_directions, d_targets, n, d_lit, stream=0):
+        """rt_visibility_device: raw device pointers (ints); uint8 [n] verdicts; enqueued only."""
+        _check(lib().rt_visibility_device(self._h, C.c_void_p(d_origins), C.c_void_p(d_directions), C.c_void_p(d_targets), int(n),
+                                          C.c_void_p(d_lit), C.c_void_p(stream or None)), self._h)
 
     def initial_rays(self, width, height):
         src = np.empty((width * height, 3))

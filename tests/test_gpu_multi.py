@@ -72,3 +72,45 @@ def test_overlapped_schedule_at_the_largest_and_smallest_frames(bench_ctx):
         for key in ("rays", "hits", "reflect_rays", "levels"):
             assert sa[key] == sb[key], key
     assert ctx.voided_frames() == 0
+
+
+def test_batched_queries_on_torch_tensors_equal_the_host_buffer_forms(bench_ctx):
+    """rt_intersect_device / rt_visibility_device on CUDA tensors (no PCIe, no allocation in the library) against
+    rt_intersect / rt_visibility on the same rays; 2 M jittered shadow rays of a camera pass, timed."""
+    ctx = bench_ctx
+    w, h = 640, 360
+    src, dirs = ctx.initial_rays(w, h)
+    pts, ids = ctx.intersect(src, dirs)
+    hit = ids != 0
+    P = pts[hit]
+    rng = np.random.default_rng(3)
+    light = np.array([0.0, 40.0, 0.0]) + rng.uniform(-1, 1, (len(P), 3))
+    vec = P - light
+    d = vec / (np.linalg.norm(vec, axis=-1, keepdims=True) + 1e-6)
+    reps = max(1, 2_000_000 // len(P))
+    O, D, T = (np.ascontiguousarray(np.tile(a, (reps, 1))) for a in (light, d, P))
+    n = len(O)
+    lit_host = ctx.visibility(O, D, T)
+    pts_host, ids_host = ctx.intersect(O, D)
+    tO, tD, tT = (torch.from_numpy(a).to("cuda:0") for a in (O, D, T))
+    t_pts = torch.empty((n, 3), dtype=torch.float64, device="cuda:0")
+    t_ids = torch.empty(n, dtype=torch.int64, device="cuda:0")
+    t_lit = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    st = torch.cuda.Stream()
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    torch.cuda.synchronize()
+    alloc_before = native.lib().rt_debug_alloc_calls()
+    with torch.cuda.stream(st):
+        e0.record(st)
+        ctx.intersect_device(tO.data_ptr(), tD.data_ptr(), n, t_pts.data_ptr(), t_ids.data_ptr(), stream=st.cuda_stream)
+        e1.record(st)
+        ctx.visibility_device(tO.data_ptr(), tD.data_ptr(), tT.data_ptr(), n, t_lit.data_ptr(), stream=st.cuda_stream)
+        e2.record(st)
+    torch.cuda.synchronize()
+    assert native.lib().rt_debug_alloc_calls() == alloc_before
+    assert np.array_equal(t_ids.cpu().numpy(), ids_host)
+    assert np.array_equal(t_pts.cpu().numpy(), pts_host, equal_nan=True)
+    assert np.array_equal(t_lit.cpu().numpy().astype(bool), lit_host)
+    assert 0.05 < lit_host.mean() < 0.99
+    print("device queries, %d rays: nearest hit %.3f ms, any hit %.3f ms" % (n, e0.elapsed_time(e1), e1.elapsed_time(e2)))
+    assert e0.elapsed_time(e2) < 20.0        # (a PCIe round trip of these buffers alone takes longer)
