@@ -139,6 +139,8 @@ typedef struct rt_render_params {
                                       instead of the per-(hit,light) beam + float32 filtered predicates */
 #define RT_FLAG_NO_OVERLAP 8       /* diagnostic: run the recursion levels strictly one after the other (the default lets the
                                       deeper levels run beside the soft shadows of level 0); same result */
+#define RT_FLAG_NO_SMALL 16         /* diagnostic: scenes small enough for the LDS-resident fused path (one kernel per level, used for
+                                      s*s <= 4) take the general wavefront pipeline instead; same result */
 #define RT_FLAG_PROFILE 2          /* bracket every kernel launch with HIP events on the launch stream and
                                       report per-family device time in rt_stats (used by bench.py's roofline) */
 

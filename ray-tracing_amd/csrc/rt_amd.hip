@@ -42,6 +42,7 @@
 #include "rt_device.hpp"
 #include "rt_fast.hpp"
 #include "rt_shadow.hpp"
+#include "rt_small.hpp"
 
 #define RT_BLOCK 256
 #define RT_HIT_RUN 256u        // hits a wave parks before it appends them to the hit list (k_intersect, camera-ray pass)
@@ -1228,6 +1229,191 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, LevelParams lp, Ra
     }
 }
 
+// One recursion level of a small scene, fused (rt_small.hpp): nearest hit, soft shadows, Phong and child rays of every
+// queued ray in one kernel, the scene tables in LDS.  GEN: level 0 of a frame, camera rays made here (ray_functions.py:7-43);
+// its shading is STORED into fb (= the frame's fb0, one hit per slot) and the other two framebuffers are zeroed on the way.
+// Framebuffers as in the general pipeline: fb <- shading (+ background the children of the last level would return),
+// fbm <- background of rays of levels >= 1 that miss.
+template <bool GEN>
+__global__ void __launch_bounds__(RT_BLOCK) k_small_level(DScene S, SmallLayout L, LevelParams lp, RayQ q, RayQ qn, FrameCtl *ctl, double *fb,
+                                                          double *fbm, double *fb_side, int32_t *ids_out, GenParams gp) {
+    extern __shared__ uint2 lds_stack[];
+    const LdsScene V = stage_scene(S, L, (RT_LDS unsigned char *)lds_stack);
+    if (ctl->overflow) return;
+    const uint32_t n = GEN ? gp.n_slots : min(ctl->n_rays[lp.level], lp.cap);
+    if (GEN && blockIdx.x == 0 && threadIdx.x == 0) ctl->n_rays[0] = gp.n_slots;
+    ChunkWalk walk(n);
+    uint64_t first;
+    const int lane = threadIdx.x & 63;
+    unsigned long long valid_total = 0, n_refl = 0, n_trans = 0, n_hit = 0;
+    const uint32_t s = (uint32_t)lp.sh_rays, s2 = s * s;
+    while (walk.next(first)) {
+        const uint64_t k = first + threadIdx.x;
+        bool active = k < n;
+        uint32_t slot = RT_INVALID_SLOT, gpix = 0, path = 1u;
+        d3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), thr = mk3(1.0, 1.0, 1.0);
+        if (GEN) {
+            const bool in_range = active;
+            if (active) active = gen_ray<false>(gp, q, k, o, d, slot);      // (the queue entry is written for rt_initial_rays-style readers: direction, slot, pixel)
+            valid_total += active ? 1ull : 0ull;
+            const uint32_t zs = active ? slot : ((in_range && gp.world > 1) ? (uint32_t)k : RT_INVALID_SLOT);
+            if (zs != RT_INVALID_SLOT) {
+                if (!active) { fb[3ull * zs] = 0.0; fb[3ull * zs + 1] = 0.0; fb[3ull * zs + 2] = 0.0; }
+                fbm[3ull * zs] = 0.0; fbm[3ull * zs + 1] = 0.0; fbm[3ull * zs + 2] = 0.0;
+                fb_side[3ull * zs] = 0.0; fb_side[3ull * zs + 1] = 0.0; fb_side[3ull * zs + 2] = 0.0;
+            }
+            if (active) gpix = gp.world > 1 ? q.gpix[k] : slot;           // (whole frames: the slot IS the global pixel index)
+        } else {
+            slot = active ? q.slot[k] : RT_INVALID_SLOT;
+            active = active && slot != RT_INVALID_SLOT;
+            if (active) {
+                o = mk3(q.ox[k], q.oy[k], q.oz[k]);
+                d = mk3(q.dx[k], q.dy[k], q.dz[k]);
+                thr = mk3(q.tr[k], q.tg[k], q.tb[k]);
+                gpix = q.gpix[k]; path = q.path[k];
+            }
+        }
+        int n_child = 0;
+        d3 o_t, d_t, thr_t, o_r, d_r, thr_r;
+        bool want_t = false, want_r = false;
+        double *fb_children = GEN ? fb_side : fb;       // where the background of the last level's would-be children goes (k_shade: ctx->fb)
+        if (active) {
+            const Hit hit = nearest_hit_small(S, V, o, d);
+            if (ids_out && lp.level == 0) ids_out[slot] = hit.id;
+            if (hit.id == 0) {
+                // ray_tracer.py:65,72,132: misses keep the background colour
+                if (GEN) { fb[3ull * slot] = S.bg[0]; fb[3ull * slot + 1] = S.bg[1]; fb[3ull * slot + 2] = S.bg[2]; }
+                else fb_add(fbm, slot, thr * ld3(S.bg));
+            } else {
+                n_hit++;
+                const d3 P = hit.p;
+                int32_t mi;
+                const d3 N = surface_normal_small(S, V, hit.id, P, mi);      // ray_tracer.py:77-78
+                d3 Kd = mk3(0, 0, 0), Ks = mk3(0, 0, 0), Kr = mk3(0, 0, 0);
+                double T = 0;
+                int32_t phong = 0, mflags = 0;
+                if (mi >= 0 && mi < S.n_mats) {                              // Material.py:23-62
+                    const DMat M = lds_load(V.mats + mi);
+                    Kd = ld3(M.kd); Ks = ld3(M.ks); Kr = ld3(M.kr);
+                    T = M.T; phong = M.phong; mflags = M.flags;
+                }
+                const d3 Vv = neg3(d);
+                const d3 Nh = N / norm3(N);                                  // ray_functions.py:98-99
+                d3 diff = mk3(0, 0, 0), spec = mk3(0, 0, 0);
+                for (int m = 0; m < S.n_lights; ++m) {
+                    const DLight Lt = lds_load(V.lights + m);
+                    const d3 dl = ld3(Lt.pos) - P;                           // Light.py:35-53
+                    const d3 Ld = dl / norm3(dl);
+                    double I = 1.0;                                          // Light.py:199-200
+                    if (Lt.shadow != 0) {
+                        d3 up, right, p00;
+                        exact_basis(Lt, lp.sh_rays, P, up, right, p00);      // Light.py:252-260
+                        const double gsz = Lt.radius / (double)(int)s;
+                        uint32_t cnt = 0;
+                        for (uint32_t kk = 0; kk < s2; ++kk) {
+                            const uint32_t a = kk / s, b = kk % s;
+                            d3 src = (p00 - ((double)b * gsz) * up) + ((double)a * gsz) * right;   // Light.py:273-274
+                            d3 u1 = mk3(0, 0, 0), u2 = mk3(0, 0, 0);
+                            if (lp.jitter) {
+                                u1 = jitter3(lp.seed, gpix, path, (uint32_t)m, kk, 0u, gsz);
+                                u2 = jitter3(lp.seed, gpix, path, (uint32_t)m, kk, 1u, gsz);
+                            }
+                            src = src + (u1 * up + u2 * right);              // Light.py:277-279
+                            const d3 vec = P - src;
+                            const d3 dir = vec / (norm3(vec) + RT_EPSILON);  // Light.py:283-286
+                            const Hit x = nearest_hit_small(S, V, src, dir);
+                            cnt += (norm3(x.p - P) < RT_EPSILON) ? 1u : 0u;  // Light.py:219-221 (NaN -> unlit)
+                        }
+                        const double frac = (double)cnt / (double)(int)s2;   // Light.py:223
+                        I = (1.0 - Lt.shadow) + Lt.shadow * frac;            // Light.py:226
+                    }
+                    I = I < 0 ? 0 : (I > 1 ? 1 : I);                         // Light.py:84
+                    const d3 col = ld3(Lt.color);
+                    const d3 Ims = (Lt.spec * I) * col;                      // Light.py:87
+                    const d3 Imd = I * col;                                  // Light.py:91
+                    double ldn = dot3(Ld, N);                                // Light.py:123-125
+                    ldn = isnan(ldn) ? ldn : (ldn > 0 ? ldn : 0);
+                    const d3 dterm = (ldn * Kd) * Imd;
+                    diff = (m == 0) ? dterm : diff + dterm;
+                    const double dp = dot3(Ld, Nh);                          // ray_functions.py:101-103
+                    const d3 R = (2 * dp) * Nh - Ld;
+                    const double rv = dot3(R, Vv);                           // Light.py:169
+                    const double pw = ipow(rv, phong);
+                    const d3 sterm = (pw * Ks) * Ims;                        // Light.py:171
+                    spec = (m == 0) ? sterm : spec + sterm;
+                }
+                spec = mk3(nan_to_num(spec.x), nan_to_num(spec.y), nan_to_num(spec.z));   // Light.py:173
+                const double nt = 1.0 - T;
+                const d3 base = (diff + spec) * mk3(nt, nt, nt);             // ray_tracer.py:105-106
+                if (GEN) {
+                    const d3 v = thr * base;
+                    fb[3ull * slot] = v.x; fb[3ull * slot + 1] = v.y; fb[3ull * slot + 2] = v.z;
+                } else fb_add(fb, slot, thr * base);
+                if (mflags & 1) {                                            // ray_tracer.py:108-116
+                    thr_t = thr * mk3(T, T, T);
+                    if (lp.last_level) fb_add(fb_children, slot, thr_t * ld3(S.bg));
+                    else { want_t = true; d_t = d; o_t = P + RT_EPSILON * d; }
+                }
+                if (mflags & 2) {                                            // ray_tracer.py:119-129
+                    thr_r = thr * Kr;
+                    if (lp.last_level) fb_add(fb_children, slot, thr_r * ld3(S.bg));
+                    else {
+                        want_r = true;
+                        const double dp = dot3(Vv, Nh);
+                        d_r = (2 * dp) * Nh - Vv;                            // ray_functions.py:103
+                        o_r = P + RT_EPSILON * d_r;
+                    }
+                }
+                n_child = (want_t ? 1 : 0) + (want_r ? 1 : 0);
+            }
+        }
+        // wave-level exclusive prefix sum of n_child -> one atomic per wave on the next queue's tail
+        int incl = n_child;
+        for (int off = 1; off < 64; off <<= 1) {
+            int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        const int total = __shfl(incl, 63);
+        if (total) {
+            uint32_t base = 0;
+            if (lane == 63) base = atomicAdd(&ctl->n_rays[lp.level + 1], (uint32_t)total);
+            base = __shfl(base, 63);
+            uint32_t w = base + (uint32_t)(incl - n_child);
+            if (base + (uint32_t)total > lp.cap) {
+                if (lane == 63) ctl->overflow = 1;     // frame is invalid; host re-renders with larger queues
+            } else {
+                if (want_t) {
+                    qn.ox[w] = o_t.x; qn.oy[w] = o_t.y; qn.oz[w] = o_t.z;
+                    qn.dx[w] = d_t.x; qn.dy[w] = d_t.y; qn.dz[w] = d_t.z;
+                    qn.tr[w] = thr_t.x; qn.tg[w] = thr_t.y; qn.tb[w] = thr_t.z;
+                    qn.slot[w] = slot; qn.gpix[w] = gpix; qn.path[w] = path * 2u;
+                    w++;
+                    n_trans++;
+                }
+                if (want_r) {
+                    qn.ox[w] = o_r.x; qn.oy[w] = o_r.y; qn.oz[w] = o_r.z;
+                    qn.dx[w] = d_r.x; qn.dy[w] = d_r.y; qn.dz[w] = d_r.z;
+                    qn.tr[w] = thr_r.x; qn.tg[w] = thr_r.y; qn.tb[w] = thr_r.z;
+                    qn.slot[w] = slot; qn.gpix[w] = gpix; qn.path[w] = path * 2u + 1u;
+                    n_refl++;
+                }
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        n_refl += __shfl_down(n_refl, off);
+        n_trans += __shfl_down(n_trans, off);
+        n_hit += __shfl_down(n_hit, off);
+        valid_total += __shfl_down(valid_total, off);
+    }
+    if (lane == 0) {
+        if (n_refl) atomicAdd(&ctl->reflect_rays, n_refl);
+        if (n_trans) atomicAdd(&ctl->transmit_rays, n_trans);
+        if (n_hit) atomicAdd(&ctl->n_hits[lp.level], (uint32_t)n_hit);
+        if (GEN && valid_total) atomicAdd(&ctl->primary_rays, valid_total);
+    }
+}
+
 // clip(0,1) (ray_tracer.py:30) and save_image's truncating quantisation (util.py:98)
 // fb0: what the level-0 rays add themselves (background of the misses, Phong term of the hits); fb: everything the
 // deeper levels add.  Two buffers keep the sum independent of how the two halves of the frame are scheduled.
@@ -1438,6 +1624,9 @@ struct rt_ctx : FrameState {
     DScene S{};
     FastScene F{};
     size_t lds_bytes = 0;   // per-lane traversal stacks: F.depth * RT_BLOCK * 8
+    SmallLayout small{};    // scene tables staged in LDS by k_small_level (rt_small.hpp); small_ok: they fit
+    bool small_ok = false;
+    int g_small = 2048;
     rt_scene_desc host{};   // scalar fields only (camera, settings)
     uint64_t fb_slots_frame = 0;   // primary slots of the frame being enqueued
     double growth = 2.0;    // queue capacity = growth * primary slots
@@ -1920,6 +2109,31 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
     }
     for (int k = 0; k < 3; ++k) ctx->S.bg[k] = s->background[k];
     tick("surface / material / light tables");
+    {
+        // small scenes: the tables k_small_level copies into LDS (rt_small.hpp)
+        auto up16 = [](size_t b) { return (uint32_t)((b + 15) & ~(size_t)15); };
+        SmallLayout &L = ctx->small;
+        uint32_t off = 0;
+        L.planes = off; off += up16((size_t)s->n_planes * sizeof(DPlane));
+        L.nodes = off; off += up16((size_t)nn * sizeof(DNode));
+        L.leaf = off; off += up16((size_t)s->n_leaf_refs * sizeof(int32_t));
+        L.prims = off; off += up16((size_t)(ns + nb) * sizeof(DPrim));
+        L.surfs = off; off += up16((size_t)s->n_surfaces * sizeof(DSurf));
+        L.mats = off; off += up16((size_t)s->n_materials * sizeof(DMat));
+        L.lights = off; off += up16((size_t)s->n_lights * sizeof(DLight));
+        L.shadow_lights = off; off += up16(sl.size() * sizeof(int32_t));
+        L.total = off;
+        const size_t raw = (size_t)s->n_planes * sizeof(DPlane) + (size_t)nn * sizeof(DNode) + (size_t)(ns + nb) * sizeof(DPrim) +
+                           (size_t)s->n_surfaces * sizeof(DSurf);
+        ctx->small_ok = raw <= RT_SMALL_LDS_MAX && off <= RT_SMALL_LDS_MAX && !getenv("RT_AMD_NO_SMALL");
+        if (ctx->small_ok) {
+            int nbk = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, (const void *)&k_small_level<true>, RT_BLOCK, L.total) != hipSuccess || nbk < 1) nbk = 1;
+            if (nbk > 6) nbk = 6;
+            ctx->g_small = (ctx->n_cu * nbk + 7) & ~7;
+        }
+        if (ctx->env.debug) fprintf(stderr, "[rt_amd] small-scene path: %s (%u B of tables), grid %d\n", ctx->small_ok ? "on" : "off", L.total, ctx->g_small);
+    }
     if (const char *lim = getenv("RT_AMD_SETS")) ctx->env_sets = atoi(lim);      // 1, 2 or 3 buffer sets (diagnostic)
     if (getenv("RT_AMD_ONE_SET")) ctx->env_sets = 1;
     ctx->host = *s;   // pointers inside are NOT used after this call; scalars (camera, settings) are
@@ -2282,6 +2496,27 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         else hipLaunchKernelGGL((k_intersect<false, false>), dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, none, bc, nullptr, nullptr);
     };
     auto queue_of = [&](int level) -> RayQ & { return level == 0 ? ctx->q[0] : ctx->q[1 + ((level - 1) & 1)]; };
+
+    // Small scene, few shadow rays per hit: one fused kernel per level over the LDS-resident scene (rt_small.hpp).  The
+    // diagnostic flags keep selecting the general pipeline, which the parity tests compare this path with.
+    const bool small = ctx->small_ok && !prof && (s2 <= 4 || ctx->S.n_shadow_lights == 0) &&
+                       !(p->flags & (RT_FLAG_EXACT_TRAVERSAL | RT_FLAG_NO_BEAM | RT_FLAG_NO_SMALL));
+    if (small) {
+        static const GenParams none{};
+        for (int level = 0; level <= rec; ++level) {
+            lp.level = level;
+            lp.last_level = (level == rec) ? 1 : 0;
+            RayQ &qc = queue_of(level), &qn = queue_of(level + 1);
+            if (level == 0 && gen)
+                hipLaunchKernelGGL(k_small_level<true>, dim3(ctx->g_small), block, ctx->small.total, st, ctx->S, ctx->small, lp, qc, qn, ctx->ctl, fb0, fbm,
+                                   ctx->fb, d_ids, *gen);
+            else
+                hipLaunchKernelGGL(k_small_level<false>, dim3(ctx->g_small), block, ctx->small.total, st, ctx->S, ctx->small, lp, qc, qn, ctx->ctl, ctx->fb, fbm,
+                                   ctx->fb, level == 0 ? d_ids : nullptr, none);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        return RT_OK;
+    }
 
     if (!overlap) {
         for (int level = 0; level <= rec; ++level) {
