@@ -127,7 +127,7 @@ def test_flag_constants_match_the_header():
     for name, value in flags.items():
         assert getattr(abi, name) == int(value), name
     values = sorted(int(v) for v in flags.values())
-    assert values == [1, 2, 4, 8]
+    assert values == [1, 2, 4, 8, 16]
 
 
 def test_no_gpu_is_an_error_not_a_fallback():
