@@ -143,7 +143,7 @@ __device__ __forceinline__ void fb_add(double *fb, uint32_t slot, d3 c) {
 // first, over every node whose box passes the slab test -> leaf primitives in list order; a
 // candidate replaces the current best only when its Euclidean distance is STRICTLY smaller.
 // Pre-order layout + skip links make the left-first DFS a linear walk without a stack.
-__device__ __noinline__ Hit nearest_hit_exact(const DScene &S, d3 o, d3 d) {
+__device__ __forceinline__ Hit nearest_hit_exact(const DScene &S, d3 o, d3 d) {
     Hit best;
     if (S.far_clip) {
         best.p = mk3(RT_MAX_RENDER_DISTANCE, RT_MAX_RENDER_DISTANCE, RT_MAX_RENDER_DISTANCE);
