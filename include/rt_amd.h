@@ -141,6 +141,8 @@ typedef struct rt_render_params {
                                       deeper levels run beside the soft shadows of level 0); same result */
 #define RT_FLAG_NO_SMALL 16         /* diagnostic: scenes small enough for the LDS-resident fused path (one kernel per level, used for
                                       s*s <= 4) take the general wavefront pipeline instead; same result */
+#define RT_FLAG_TIME_DOMINANT 32   /* HIP events around the k_beam_setup launches only, schedule unchanged (levels stay overlapped):
+                                      rt_stats.ms_beam_setup / beam_setup_launches of that frame (bench.py: live duration of the dominant kernel) */
 #define RT_FLAG_PROFILE 2          /* bracket every kernel launch with HIP events on the launch stream and
                                       report per-family device time in rt_stats (used by bench.py's roofline) */
 
@@ -155,8 +157,8 @@ typedef struct rt_stats {
     double ms_intersect, ms_shadow, ms_shade; /* per kernel family, summed over levels (RT_FLAG_PROFILE only) */
     double ms_gen, ms_resolve;   /* RT_FLAG_PROFILE only */
     int64_t launches_per_family; /* RT_FLAG_PROFILE only: number of k_intersect (= k_shadow = k_shade) launches */
-    double ms_beam_setup;        /* RT_FLAG_PROFILE only: HIP events around the k_beam_setup launches alone (the frame's dominant kernel) */
-    int64_t beam_setup_launches; /* RT_FLAG_PROFILE only */
+    double ms_beam_setup;        /* RT_FLAG_PROFILE / RT_FLAG_TIME_DOMINANT: HIP events around the k_beam_setup launches alone (the frame's dominant kernel) */
+    int64_t beam_setup_launches; /* RT_FLAG_PROFILE / RT_FLAG_TIME_DOMINANT */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

@@ -2374,12 +2374,16 @@ static int prof_prepare(rt_ctx *ctx, int levels) {
         HIP_TRY(ctx, rt_event_create(&e, true));
         ctx->prof_ev.push_back(e);
     }
+    ctx->prof_levels = levels;
+    return RT_OK;
+}
+// events around the k_beam_setup launches alone (RT_FLAG_PROFILE and RT_FLAG_TIME_DOMINANT)
+static int prof_bs_prepare(rt_ctx *ctx, int levels) {
     while (ctx->prof_bs.size() < 2 * (size_t)levels) {
         hipEvent_t e;
         HIP_TRY(ctx, rt_event_create(&e, true));
         ctx->prof_bs.push_back(e);
     }
-    ctx->prof_levels = levels;
     ctx->prof_bs_levels = 0;
     return RT_OK;
 }
@@ -2420,6 +2424,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
     }
     dim3 block(RT_BLOCK);
     const bool prof = (p->flags & RT_FLAG_PROFILE) != 0;
+    const bool time_bs = (prof || (p->flags & RT_FLAG_TIME_DOMINANT)) && ctx->prof_bs.size() >= 2 * (size_t)(rec + 1);
     const bool fast = ctx->F.ok && !(p->flags & RT_FLAG_EXACT_TRAVERSAL);
     const uint32_t s2 = (uint32_t)(sh * sh);
     const bool beam = fast && ctx->S.n_planes <= RT_PMAX && !(p->flags & RT_FLAG_NO_BEAM) && s2 >= 9 && s2 <= RT_BLOCK &&
@@ -2458,12 +2463,12 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                 // the kernel template that fits the scene: long beams or not, boxes or spheres only
                 const dim3 gs(gsz(ctx->g_beam_setup, ctx->nb_beam_setup, side));
                 const bool boxes = ctx->n_boxes > 0 || ctx->env.box_kernels;
-                if (prof) HIP_TRY(ctx, hipEventRecord(ctx->prof_bs[2 * level], s_));      // the frame's dominant kernel on its own (bench.py: roofline)
+                if (time_bs) HIP_TRY(ctx, hipEventRecord(ctx->prof_bs[2 * level], s_));      // the frame's dominant kernel on its own (bench.py: roofline)
                 if (lp.beam_early && boxes) hipLaunchKernelGGL((k_beam_setup<true, true>), gs, block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
                 else if (lp.beam_early) hipLaunchKernelGGL((k_beam_setup<true, false>), gs, block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
                 else if (boxes) hipLaunchKernelGGL((k_beam_setup<false, true>), gs, block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
                 else hipLaunchKernelGGL((k_beam_setup<false, false>), gs, block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
-                if (prof) { HIP_TRY(ctx, hipEventRecord(ctx->prof_bs[2 * level + 1], s_)); ctx->prof_bs_levels = level + 1; }
+                if (time_bs) { HIP_TRY(ctx, hipEventRecord(ctx->prof_bs[2 * level + 1], s_)); ctx->prof_bs_levels = level + 1; }
             }
             hipLaunchKernelGGL(k_shadow_beam, dim3(gsz(ctx->g_beam, ctx->nb_beam, side == 1 ? 3 : side)), block, 0, s_, ctx->S, lp, hb, bb, ctx->ctl);
             // k_shadow_walk only where the last frame of this shape had work for it (rt_ctx::seen_walk); without the launch
@@ -2681,6 +2686,8 @@ extern "C" int rt_render_device(rt_ctx *ctx, const rt_render_params *p, float *d
     const bool prof = (p->flags & RT_FLAG_PROFILE) != 0 && rec >= 0;
     ctx->prof_levels = -1;
     if (prof) { if (int rc = prof_prepare(ctx, rec + 1)) return rc; }
+    ctx->prof_bs_levels = 0;
+    if ((prof || (p->flags & RT_FLAG_TIME_DOMINANT)) && rec >= 0) { if (int rc = prof_bs_prepare(ctx, rec + 1)) return rc; }
     ctx->last_noalloc = false;
     return enqueue_frame(ctx, p, g, sh, rec, d_rgb, d_rgb8, d_ids, st, prof);
 }
@@ -2698,7 +2705,8 @@ extern "C" int rt_render_device_noalloc(rt_ctx *ctx, const rt_render_params *p, 
     if (int rc = tile_geom(p, g, why)) return fail(ctx, rc, why);
     int32_t sh, rec;
     if (int rc = resolve_settings(ctx, p, sh, rec)) return rc;
-    if (p->flags & RT_FLAG_PROFILE) return fail(ctx, RT_ERR_UNSUPPORTED, "RT_FLAG_PROFILE creates events: not available on the no-alloc entry point");
+    if (p->flags & (RT_FLAG_PROFILE | RT_FLAG_TIME_DOMINANT)) return fail(ctx, RT_ERR_UNSUPPORTED, "RT_FLAG_PROFILE / RT_FLAG_TIME_DOMINANT create events: not available on the no-alloc entry point");
+    ctx->prof_bs_levels = 0;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     unsigned char *base = nullptr;
     if (int rc = scratch_address(ctx, ctx->device, &base)) return rc;
@@ -2769,12 +2777,12 @@ extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
             }
             stats->ms_resolve = span(2 + 6 * ctx->prof_levels);
             stats->launches_per_family = ctx->prof_levels;
-            for (int l = 0; l < ctx->prof_bs_levels; ++l) {
-                float t = 0;
-                if (hipEventElapsedTime(&t, ctx->prof_bs[2 * l], ctx->prof_bs[2 * l + 1]) == hipSuccess) stats->ms_beam_setup += t;
-            }
-            stats->beam_setup_launches = ctx->prof_bs_levels;
         }
+        for (int l = 0; l < ctx->prof_bs_levels; ++l) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, ctx->prof_bs[2 * l], ctx->prof_bs[2 * l + 1]) == hipSuccess) stats->ms_beam_setup += t;
+        }
+        stats->beam_setup_launches = ctx->prof_bs_levels;
     }
     if (ctx->env.debug && ctx->beam.rec && c.n_hits[0] > 0) {
         // beam path diagnostics: per level, pairs / pairs that needed the per-ray filter / rays that needed float64
@@ -2967,7 +2975,8 @@ extern "C" int rt_trace(rt_ctx *ctx, const rt_render_params *p, const double *or
         } else {
             hipLaunchKernelGGL(k_load_rays, dim3(ctx->grid), dim3(RT_BLOCK), 0, st, d_o, d_d, (uint32_t)n, ctx->q[0], ctx->ctl);
             rt_render_params pp = *p;
-            pp.flags &= ~RT_FLAG_PROFILE;
+            pp.flags &= ~(RT_FLAG_PROFILE | RT_FLAG_TIME_DOMINANT);
+            ctx->prof_bs_levels = 0;
             ctx->prof_levels = -1;
             rc = enqueue_levels(ctx, &pp, sh, rec, nullptr, st, ctx->fb, nullptr, ctx->fb);   // one framebuffer: rgb_out is its raw float64 content
             if (rc != RT_OK) break;
