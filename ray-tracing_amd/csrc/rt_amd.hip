@@ -1593,6 +1593,7 @@ struct EnvCfg {
     bool box_kernels = false;           // RT_AMD_BOX_KERNELS: box-capable kernel templates even without boxes
     bool no_prio = false, prio = false; // RT_AMD_NO_PRIO / RT_AMD_PRIO: wave priority of the deeper levels
     bool no_pipeline = false;           // RT_AMD_NO_PIPELINE: deeper levels on one stream
+    bool one_shadow_stream = false;     // RT_AMD_ONE_SHADOW_STREAM: soft shadows of all deeper levels on stream3 (diagnostic)
     bool debug = false;                 // RT_AMD_DEBUG: per-level diagnostics on stderr
     bool exact = false;                 // RT_AMD_EXACT: batched queries through the reference-order walk
     int ovl_main = 3, ovl_side = 1, ovl_main2 = 3;   // RT_AMD_OVL_*: workgroups per CU of the two sides of an overlapped frame
@@ -1602,6 +1603,7 @@ struct EnvCfg {
         box_kernels = getenv("RT_AMD_BOX_KERNELS") != nullptr;
         no_prio = getenv("RT_AMD_NO_PRIO") != nullptr; prio = getenv("RT_AMD_PRIO") != nullptr;
         no_pipeline = getenv("RT_AMD_NO_PIPELINE") != nullptr;
+        one_shadow_stream = getenv("RT_AMD_ONE_SHADOW_STREAM") != nullptr;
         debug = getenv("RT_AMD_DEBUG") != nullptr;
         exact = getenv("RT_AMD_EXACT") != nullptr;
         if (const char *e = getenv("RT_AMD_OVL_MAIN")) ovl_main = atoi(e);
@@ -1635,7 +1637,8 @@ struct rt_ctx : FrameState {
     uint64_t frame_bytes = 0;               // device bytes of the frame state (ensure_frame)
     int env_sets = 0;                       // RT_AMD_SETS / RT_AMD_ONE_SET, read once in rt_create (0 = no limit)
     FrameCtl *ctl_own = nullptr;            // the context's own counter block (FrameState::ctl points here outside a no-alloc frame)
-    hipStream_t stream3 = nullptr;          // soft shadows + Phong of levels 1.. in a pipelined frame
+    hipStream_t stream3 = nullptr;          // soft shadows + Phong of the odd levels 1, 3, .. in a pipelined frame
+    hipStream_t stream4 = nullptr;          // ... of the even levels 2, 4, ..
     std::vector<hipEvent_t> ev_hit, ev_lit; // per level: nearest hits known / shading added
     double *acc = nullptr;                  // rt_render_mean: sum of the clipped frames
     uint64_t acc_slots = 0;
@@ -1829,6 +1832,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
     // gives the same bias without a second queue priority.)
     HIP_C(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
     HIP_C(hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
+    HIP_C(hipStreamCreateWithFlags(&ctx->stream4, hipStreamNonBlocking));
     HIP_C(rt_event_create(&ctx->ev_fork, false));
     HIP_C(rt_event_create(&ctx->ev_join, false));
     ctx->env.read();
@@ -2172,6 +2176,7 @@ extern "C" int rt_destroy(rt_ctx *ctx) {
     for (hipEvent_t e : ctx->ev_lit) (void)hipEventDestroy(e);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
+    if (ctx->stream4) (void)hipStreamDestroy(ctx->stream4);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RT_OK;
@@ -2562,7 +2567,9 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                            ctx->beam.litbits, ctx->beam.pair_slot, ctx->beam.queue_n);
         const bool no_pipe = ctx->env.no_pipeline;
         if (ctx->three_sets && rec >= 2 && !no_pipe) {
-            hipStream_t s3_ = ctx->stream3;
+            // Soft shadows of consecutive levels run side by side (odd levels on stream3, even levels on stream4: each is a latency
+            // chain of its own); the Phong terms still reach fb in level order - shade(L) waits for shade(L - 1) - so the
+            // float64 sums do not depend on the schedule.
             while ((int)ctx->ev_hit.size() <= rec) {
                 hipEvent_t a, b;
                 HIP_TRY(ctx, rt_event_create(&a, false));
@@ -2585,8 +2592,10 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                 if (level < rec)
                     hipLaunchKernelGGL(k_shade<RT_SHADE_SPAWN>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s2_, ctx->S, lp, qc, qn, hb, ctx->ctl, ctx->fb,
                                        bb.litbits, bb.pair_slot, bb.queue_n);
+                hipStream_t s3_ = (odd || ctx->env.one_shadow_stream) ? ctx->stream3 : ctx->stream4;
                 HIP_TRY(ctx, hipStreamWaitEvent(s3_, ctx->ev_hit[level], 0));
                 if (int rc = shadows(level, s3_, qc, hb, sg, bb, 2)) return rc;
+                if (level >= 2) HIP_TRY(ctx, hipStreamWaitEvent(s3_, ctx->ev_lit[level - 1], 0));
                 if (level < rec)
                     hipLaunchKernelGGL(k_shade<RT_SHADE_LIGHTS>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s3_, ctx->S, lp, qc, qn, hb, ctx->ctl, ctx->fb,
                                        bb.litbits, bb.pair_slot, bb.queue_n);
@@ -2596,7 +2605,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_lit[level], s3_));
             }
             lp.prio = 0;
-            HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_lit[rec], 0));      // stream3 is in level order: the last one covers all
+            HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_lit[rec], 0));      // shade(L) follows shade(L - 1): the last one covers all
         } else {
             for (int level = 1; level <= rec; ++level) {
                 RayQ &qc = queue_of(level), &qn = queue_of(level + 1);
