@@ -57,6 +57,7 @@ struct FrameCtl {
     uint32_t n_hits[RT_MAX_LEVELS + 2];
     uint32_t overflow;
     uint32_t overflow_q;                    // ... and it was the float64 shadow-ray queue (bb.queue) that ran out
+    uint32_t overflow_deep, overflow_pad;   // ... and it was the queue of a level >= 1 (sized cap_deep) that ran out
     unsigned long long reflect_rays, transmit_rays, primary_rays;
     uint32_t n_listed[RT_MAX_LEVELS + 2];   // diagnostics: pairs that needed the per-ray filter / rays that needed
     uint32_t n_queued[RT_MAX_LEVELS + 2];   // the float64 queue, per level (copied by k_shade)
@@ -95,7 +96,8 @@ struct GenParams {
 struct LevelParams {
     int32_t level, last_level;   // last_level: children are not traced, they return the background
     int32_t sh_rays, jitter;
-    uint32_t seed, cap;
+    uint32_t seed, cap;                  // cap: capacity of THIS level's ray queue and per-hit / per-pair buffers
+    uint32_t cap_next;                   // capacity of the next level's ray queue (the levels >= 1 live in smaller buffers)
     int32_t flags;
     // beam path: a chunk of RT_BLOCK lanes holds spb whole (hit, light) pairs of s2 rays each
     uint32_t spb, magic_s2, magic_s;     // magic_x = ceil(2^32 / x): n / x == __umulhi(n, magic_x) for n < 2^16
@@ -1198,8 +1200,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, LevelParams lp, Ra
             if (lane == 63) base = atomicAdd(&ctl->n_rays[lp.level + 1], (uint32_t)total);
             base = __shfl(base, 63);
             uint32_t w = base + (uint32_t)(incl - n_child);
-            if (base + (uint32_t)total > lp.cap) {
-                if (lane == 63) ctl->overflow = 1;     // frame is invalid; host re-renders with larger queues
+            if (base + (uint32_t)total > lp.cap_next) {
+                if (lane == 63) ctl->overflow = ctl->overflow_deep = 1;     // frame is invalid; host re-renders with larger queues
             } else {
                 if (want_t) {
                     qn.ox[w] = o_t.x; qn.oy[w] = o_t.y; qn.oz[w] = o_t.z;
@@ -1379,8 +1381,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_small_level(DScene S, SmallLayout 
             if (lane == 63) base = atomicAdd(&ctl->n_rays[lp.level + 1], (uint32_t)total);
             base = __shfl(base, 63);
             uint32_t w = base + (uint32_t)(incl - n_child);
-            if (base + (uint32_t)total > lp.cap) {
-                if (lane == 63) ctl->overflow = 1;     // frame is invalid; host re-renders with larger queues
+            if (base + (uint32_t)total > lp.cap_next) {
+                if (lane == 63) ctl->overflow = ctl->overflow_deep = 1;     // frame is invalid; host re-renders with larger queues
             } else {
                 if (want_t) {
                     qn.ox[w] = o_t.x; qn.oy[w] = o_t.y; qn.oz[w] = o_t.z;
@@ -1572,18 +1574,25 @@ static thread_local std::string g_create_error;
 // (ensure_frame); rt_render_device_noalloc carves it out of the library's static device array (see `scratch` below) and
 // swaps it in for the duration of the enqueue.  Trivially copyable on purpose.
 struct FrameState {
-    uint64_t cap = 0;       // ray-queue capacity
+    uint64_t cap = 0;       // ray-queue capacity of level 0 (and of every level when the levels share one buffer set)
+    uint64_t cap_deep = 0;  // ... of the levels >= 1: queues 1.., buffer sets 1.. (cap / deep_div)
     uint64_t fb_slots = 0;
     uint32_t beam_queue_cap = 0;
-    RayQ q[4]{};            // level 0 -> q[0]; level k >= 1 -> q[1 + (k - 1) % 2] (% 3 when the deeper levels are pipelined)
-    HitBuf hb{}, hb1{}, hb2{};   // level 0 / deeper levels, odd / deeper levels, even (so are seg*, beam*)
-    SegBuf seg{}, seg1{}, seg2{};
-    BeamBuf beam{}, beam1{}, beam2{};
+    double qgrowth_carved = 1.0;    // float64 shadow-ray queue of a set = its capacity * this
+    RayQ q[6]{};            // level 0 -> q[0]; level k >= 1 -> q[1 + (k - 1) % 2] (% 3 / % 5 when the deeper levels are pipelined over 2 / 4 sets)
+    HitBuf hb{}, hb1{}, hb2{}, hb3{}, hb4{};   // level 0 / deeper levels, rotating (so are seg*, beam*)
+    SegBuf seg{}, seg1{}, seg2{}, seg3{}, seg4{};
+    BeamBuf beam{}, beam1{}, beam2{}, beam3{}, beam4{};
+    bool five_sets = false;                 // hb3, hb4 / .. are separate allocations: a level's buffers are reused four levels later
     double *fb = nullptr, *fb0 = nullptr, *fbm = nullptr;   // see k_resolve
     bool two_sets = false;                  // hb1 / seg1 / beam1 are separate allocations
     bool three_sets = false;                // hb2 / seg2 / beam2 are separate allocations: levels 1.. can be pipelined
     FrameCtl *ctl = nullptr;
 };
+
+static HitBuf *hit_set(FrameState &fs, int set) { HitBuf *a[5] = {&fs.hb, &fs.hb1, &fs.hb2, &fs.hb3, &fs.hb4}; return a[set]; }
+static SegBuf *seg_set(FrameState &fs, int set) { SegBuf *a[5] = {&fs.seg, &fs.seg1, &fs.seg2, &fs.seg3, &fs.seg4}; return a[set]; }
+static BeamBuf *beam_set(FrameState &fs, int set) { BeamBuf *a[5] = {&fs.beam, &fs.beam1, &fs.beam2, &fs.beam3, &fs.beam4}; return a[set]; }
 
 // RT_AMD_* environment switches (diagnostics / experiments), read ONCE in rt_create: a frame takes ~2 ms, a getenv per
 // launch decision is host time on its critical path
@@ -1632,6 +1641,7 @@ struct rt_ctx : FrameState {
     rt_scene_desc host{};   // scalar fields only (camera, settings)
     uint64_t fb_slots_frame = 0;   // primary slots of the frame being enqueued
     double growth = 2.0;    // queue capacity = growth * primary slots
+    double deep_div = 2.0;  // cap_deep = cap / deep_div: a level >= 1 rarely holds more rays than there are camera rays (halved when one does)
     double qgrowth = 1.0;   // float64 shadow-ray queue = qgrowth * queue capacity (grows by itself: large s, many undecided rays)
     std::vector<void *> frame_allocs;
     uint64_t frame_bytes = 0;               // device bytes of the frame state (ensure_frame)
@@ -2210,28 +2220,33 @@ struct Carver {
 
 // Carve the state of a frame of `slots` primary slots with queue capacity `cap` into fs.  sets = 1..3 buffer sets (level 0 /
 // deeper levels odd / even); queues = 3 (levels in sequence) or 4 (pipelined deeper levels).  Nothing is initialised here.
-static int carve_frame(rt_ctx *ctx, Carver &mem, FrameState &fs, uint64_t slots, uint64_t cap, uint32_t queue_cap, int sets, int queues) {
+static int carve_frame(rt_ctx *ctx, Carver &mem, FrameState &fs, uint64_t slots, uint64_t cap0, uint64_t cap_deep, double qgrowth, int sets, int queues) {
 #define TRY_A(expr) do { int rc_ = (expr); if (rc_ != RT_OK) return rc_; } while (0)
+    if (sets < 2) cap_deep = cap0;          // one set: every level lives in it
+    auto qcap = [&](uint64_t c) { const double v = (double)c * qgrowth; return (uint32_t)(v < 2147483647.0 ? v : 2147483647.0); };
     for (int i = 0; i < queues; ++i) {
         RayQ &q = fs.q[i];
+        const uint64_t cap = i == 0 ? cap0 : cap_deep;
         TRY_A(mem.get(&q.ox, cap)); TRY_A(mem.get(&q.oy, cap)); TRY_A(mem.get(&q.oz, cap));
         TRY_A(mem.get(&q.dx, cap)); TRY_A(mem.get(&q.dy, cap)); TRY_A(mem.get(&q.dz, cap));
         TRY_A(mem.get(&q.tr, cap)); TRY_A(mem.get(&q.tg, cap)); TRY_A(mem.get(&q.tb, cap));
         TRY_A(mem.get(&q.slot, cap)); TRY_A(mem.get(&q.gpix, cap)); TRY_A(mem.get(&q.path, cap));
     }
-    for (int i = queues; i < 4; ++i) fs.q[i] = fs.q[queues - 1];
-    const uint64_t nlit = cap * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1);
-    fs.beam_queue_cap = queue_cap;
+    for (int i = queues; i < 6; ++i) fs.q[i] = fs.q[queues - 1];
+    const uint64_t nsl1 = (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1);
+    fs.beam_queue_cap = qcap(cap0);
     for (int set = 0; set < sets; ++set) {
-        HitBuf &hb = set == 0 ? fs.hb : (set == 1 ? fs.hb1 : fs.hb2);
+        const uint64_t cap = set == 0 ? cap0 : cap_deep, nlit = cap * nsl1;
+        const uint32_t queue_cap = qcap(cap);
+        HitBuf &hb = *hit_set(fs, set);
         TRY_A(mem.get(&hb.px, cap)); TRY_A(mem.get(&hb.py, cap)); TRY_A(mem.get(&hb.pz, cap));
         TRY_A(mem.get(&hb.id, cap)); TRY_A(mem.get(&hb.list, cap));
         TRY_A(mem.get(&hb.lit, nlit));
-        SegBuf &sg = set == 0 ? fs.seg : (set == 1 ? fs.seg1 : fs.seg2);
+        SegBuf &sg = *seg_set(fs, set);
         TRY_A(mem.get(&sg.ux, nlit)); TRY_A(mem.get(&sg.uy, nlit)); TRY_A(mem.get(&sg.uz, nlit));
         TRY_A(mem.get(&sg.rx, nlit)); TRY_A(mem.get(&sg.ry, nlit)); TRY_A(mem.get(&sg.rz, nlit));
         TRY_A(mem.get(&sg.cx, nlit)); TRY_A(mem.get(&sg.cy, nlit)); TRY_A(mem.get(&sg.cz, nlit));
-        BeamBuf &bb = set == 0 ? fs.beam : (set == 1 ? fs.beam1 : fs.beam2);
+        BeamBuf &bb = *beam_set(fs, set);
         TRY_A(mem.get(&bb.rec, (nlit + RT_BLOCK) * RT_PAIR_UNITS));   // + one chunk of slack: staging reads whole chunks
         TRY_A(mem.get(&bb.queue, (uint64_t)queue_cap)); TRY_A(mem.get(&bb.queue_n, 4));
         TRY_A(mem.get(&bb.litbits, (nlit + 1) * (RT_BLOCK / 64)));      // worst case one pair per chunk (s*s > RT_BLOCK / 2)
@@ -2239,13 +2254,17 @@ static int carve_frame(rt_ctx *ctx, Carver &mem, FrameState &fs, uint64_t slots,
     }
     if (sets < 2) { fs.hb1 = fs.hb; fs.seg1 = fs.seg; fs.beam1 = fs.beam; }
     if (sets < 3) { fs.hb2 = fs.hb1; fs.seg2 = fs.seg1; fs.beam2 = fs.beam1; }
+    if (sets < 5) { fs.hb3 = fs.hb1; fs.seg3 = fs.seg1; fs.beam3 = fs.beam1; fs.hb4 = fs.hb2; fs.seg4 = fs.seg2; fs.beam4 = fs.beam2; }
     fs.two_sets = sets >= 2;
     fs.three_sets = sets >= 3;
+    fs.five_sets = sets >= 5;
     TRY_A(mem.get(&fs.fb0, slots * 3));
     TRY_A(mem.get(&fs.fb, slots * 3));
     TRY_A(mem.get(&fs.fbm, slots * 3));
 #undef TRY_A
-    fs.cap = cap;
+    fs.cap = cap0;
+    fs.cap_deep = cap_deep;
+    fs.qgrowth_carved = qgrowth;
     fs.fb_slots = slots;
     return RT_OK;
 }
@@ -2253,13 +2272,15 @@ static int carve_frame(rt_ctx *ctx, Carver &mem, FrameState &fs, uint64_t slots,
 // what must hold before the first frame on freshly carved (or reused static) buffers: lit counters zero - k_shade resets them
 // only as it consumes them, a frame voided by a queue overflow leaves counts behind -, append counters zero, queue capacity set
 static int init_frame_counters(rt_ctx *ctx, FrameState &fs, hipStream_t st) {
-    const uint64_t nlit = fs.cap * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1);
-    const int sets = fs.three_sets ? 3 : (fs.two_sets ? 2 : 1);
+    const uint64_t nsl1 = (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1);
+    const int sets = fs.five_sets ? 5 : (fs.three_sets ? 3 : (fs.two_sets ? 2 : 1));
     for (int set = 0; set < sets; ++set) {
-        HitBuf &hb = set == 0 ? fs.hb : (set == 1 ? fs.hb1 : fs.hb2);
-        BeamBuf &bb = set == 0 ? fs.beam : (set == 1 ? fs.beam1 : fs.beam2);
-        HIP_TRY(ctx, hipMemsetAsync(hb.lit, 0, nlit * sizeof(uint32_t), st));
-        hipLaunchKernelGGL(k_init_beam_counters, dim3(1), dim3(64), 0, st, bb.queue_n, fs.beam_queue_cap);
+        HitBuf &hb = *hit_set(fs, set);
+        BeamBuf &bb = *beam_set(fs, set);
+        const uint64_t cap = set == 0 ? fs.cap : fs.cap_deep;
+        const double qd = (double)cap * fs.qgrowth_carved;
+        HIP_TRY(ctx, hipMemsetAsync(hb.lit, 0, cap * nsl1 * sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_init_beam_counters, dim3(1), dim3(64), 0, st, bb.queue_n, (uint32_t)(qd < 2147483647.0 ? qd : 2147483647.0));
     }
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
@@ -2271,7 +2292,9 @@ static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
     if (want_cap > 0xFFFFFFF0ull) return fail(ctx, RT_ERR_UNSUPPORTED, "ray queue would exceed 2^32 entries");
     const double want_qd = (double)want_cap * ctx->qgrowth;
     const uint32_t want_q = (uint32_t)(want_qd < 2147483647.0 ? want_qd : 2147483647.0);
-    if (ctx->cap >= want_cap && ctx->fb_slots >= slots && ctx->beam_queue_cap >= want_q) {
+    // the levels >= 1 hold a fraction of the camera rays (deep_div starts at 2 and is halved when they overflow)
+    const uint64_t want_deep = std::min<uint64_t>(want_cap, (uint64_t)((double)want_cap / ctx->deep_div) + 1024);
+    if (ctx->cap >= want_cap && ctx->cap_deep >= want_deep && ctx->fb_slots >= slots && ctx->beam_queue_cap >= want_q) {
         if (ctx->counters_dirty) {
             // the last frame was voided by a queue overflow: its shading kernels returned early and left lit counts behind
             // (k_shade clears them only as it consumes them); a smaller frame that fits the old buffers must not see them
@@ -2286,24 +2309,29 @@ static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
     HIP_TRY(ctx, hipDeviceSynchronize());   // rare: buffers of an in-flight frame are about to be replaced
     free_frame(ctx);
     const uint64_t cap = want_cap;
-    const uint64_t nlit = cap * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1);
-    // the second and third buffer set are speed-ups only: without the memory for them levels share a set and run in sequence
-    int sets = 3;
+    const uint64_t nsl1 = (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1);
+    // Buffer sets two to five are speed-ups only (levels overlap; a level's buffers are reused two / four levels later): without
+    // the memory for them levels share sets and run in sequence.
+    int sets = 5;
     {
         size_t free_b = 0, total_b = 0;
-        const uint64_t queues_b = 4 * cap * 84, fb_b = slots * 72;
-        const uint64_t set_b = cap * 40 + nlit * (4 + 72 + 16 * RT_PAIR_UNITS + 8 * (RT_BLOCK / 64) + 12) + (uint64_t)want_q * 8;
+        auto set_bytes = [&](uint64_t c) { return c * 40 + c * nsl1 * (4 + 72 + 16 * RT_PAIR_UNITS + 8 * (RT_BLOCK / 64) + 12) + (uint64_t)((double)c * ctx->qgrowth) * 8; };
+        const uint64_t queues_b = (cap + 5 * want_deep) * 84, fb_b = slots * 72;
+        const uint64_t set0_b = set_bytes(cap), setd_b = set_bytes(want_deep);
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) sets = 1;
         else {
             const uint64_t avail = (uint64_t)free_b > queues_b + fb_b ? (uint64_t)free_b - queues_b - fb_b : 0;
-            while (sets > 1 && avail < (uint64_t)sets * (set_b + set_b / 8)) --sets;
+            auto need = [&](int n) { const uint64_t b = set0_b + (uint64_t)(n - 1) * setd_b; return b + b / 8; };
+            while (sets > 1 && avail < need(sets)) --sets;
+            if (sets == 4) sets = 3;
         }
-        if (ctx->env_sets > 0 && ctx->env_sets < sets) sets = ctx->env_sets;      // RT_AMD_SETS = 1, 2 or 3 / RT_AMD_ONE_SET (diagnostic)
+        if (ctx->env_sets > 0 && ctx->env_sets < sets) sets = ctx->env_sets;      // RT_AMD_SETS = 1, 2, 3 or 5 / RT_AMD_ONE_SET (diagnostic)
+        if (sets == 4) sets = 3;
     }
     Carver mem{ctx};
     FrameState fs;
     fs.ctl = ctx->ctl_own;
-    int rc = carve_frame(ctx, mem, fs, slots, cap, want_q, sets, 4);
+    int rc = carve_frame(ctx, mem, fs, slots, cap, want_deep, ctx->qgrowth, sets, sets >= 5 ? 6 : 4);
     if (rc == RT_OK) rc = init_frame_counters(ctx, fs, ctx->stream);
     if (rc == RT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, RT_ERR_HIP, "hipStreamSynchronize failed after frame set-up");
     if (rc != RT_OK) { free_frame(ctx); return rc; }
@@ -2415,7 +2443,12 @@ static int prof_bs_prepare(rt_ctx *ctx, int levels) {
 static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, int32_t rec, int32_t *d_ids, hipStream_t st,
                           double *fb0, const GenParams *gen, double *fbm) {
     LevelParams lp{};
-    lp.sh_rays = sh; lp.jitter = p->jitter; lp.seed = p->seed; lp.cap = (uint32_t)ctx->cap; lp.flags = p->flags;
+    lp.sh_rays = sh; lp.jitter = p->jitter; lp.seed = p->seed; lp.cap = (uint32_t)ctx->cap; lp.cap_next = (uint32_t)ctx->cap_deep; lp.flags = p->flags;
+    auto set_level = [&](int level) {
+        lp.level = level;
+        lp.last_level = (level == rec) ? 1 : 0;
+        lp.cap = (uint32_t)(level == 0 ? ctx->cap : ctx->cap_deep);
+    };
     lp.unit_thr = gen ? 1 : 0;
     const uint64_t frame_slots = gen ? ctx->fb_slots_frame : ~0ull;     // (shape of the frame, for rt_ctx::seen_walk)
     {
@@ -2460,8 +2493,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         return (ctx->n_cu * use + 7) & ~7;
     };
     auto shadows = [&](int level, hipStream_t s_, RayQ &qc, HitBuf &hb, SegBuf &sg, BeamBuf &bb, int side) -> int {
-        lp.level = level;
-        lp.last_level = (level == rec) ? 1 : 0;
+        set_level(level);
         if (ctx->S.n_shadow_lights <= 0) return RT_OK;
         if (beam) {
             {
@@ -2493,8 +2525,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
     };
     auto intersect = [&](int level, hipStream_t s_, RayQ &qc, HitBuf &hb, double *fbx, int side_, BeamBuf &bb) {
         uint32_t *bc = beam ? bb.queue_n : nullptr;
-        lp.level = level;
-        lp.last_level = (level == rec) ? 1 : 0;
+        set_level(level);
         static const GenParams none{};
         int32_t *ids = level == 0 ? d_ids : nullptr;
         if (level == 0 && gen) {
@@ -2514,8 +2545,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
     if (small) {
         static const GenParams none{};
         for (int level = 0; level <= rec; ++level) {
-            lp.level = level;
-            lp.last_level = (level == rec) ? 1 : 0;
+            set_level(level);
             RayQ &qc = queue_of(level), &qn = queue_of(level + 1);
             if (level == 0 && gen)
                 hipLaunchKernelGGL(k_small_level<true>, dim3(ctx->g_small), block, ctx->small.total, st, ctx->S, ctx->small, lp, qc, qn, ctx->ctl, fb0, fbm,
@@ -2562,7 +2592,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         // deeper levels (stream2): few, long rays - their waves ask for issue priority over the level-0 waves
         // (in frames of many million pixels the level-0 side is the long one and the priority only slows it down)
         lp.prio = ctx->env.no_prio ? 0 : (ctx->env.prio || ctx->fb_slots_frame <= (4u << 20) ? 1 : 0);
-        lp.level = 0; lp.last_level = 0;
+        set_level(0);
         hipLaunchKernelGGL(k_shade<RT_SHADE_SPAWN>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s2_, ctx->S, lp, ctx->q[0], ctx->q[1], ctx->hb, ctx->ctl, ctx->fb,
                            ctx->beam.litbits, ctx->beam.pair_slot, ctx->beam.queue_n);
         const bool no_pipe = ctx->env.no_pipeline;
@@ -2577,15 +2607,18 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                 HIP_TRY(ctx, rt_event_create(&b, false));
                 ctx->ev_lit.push_back(b);
             }
-            auto pq = [&](int level) -> RayQ & { return ctx->q[1 + (level - 1) % 3]; };
+            // deeper levels rotate over nd = 2 or 4 buffer sets and nd + 1 ray queues
+            const int nd = ctx->five_sets ? 4 : 2;
+            auto pq = [&](int level) -> RayQ & { return ctx->q[1 + (level - 1) % (nd + 1)]; };
             for (int level = 1; level <= rec; ++level) {
                 const bool odd = (level & 1) != 0;
-                HitBuf &hb = odd ? ctx->hb1 : ctx->hb2;
-                SegBuf &sg = odd ? ctx->seg1 : ctx->seg2;
-                BeamBuf &bb = odd ? ctx->beam1 : ctx->beam2;
+                const int set = 1 + (level - 1) % nd;
+                HitBuf &hb = *hit_set(*ctx, set);
+                SegBuf &sg = *seg_set(*ctx, set);
+                BeamBuf &bb = *beam_set(*ctx, set);
                 RayQ &qc = pq(level), &qn = pq(level + 1);
-                // set and queue of level - 2 are reused: its shading must be through
-                if (level >= 3) HIP_TRY(ctx, hipStreamWaitEvent(s2_, ctx->ev_lit[level - 2], 0));
+                // set and queue of level - nd are reused: its shading must be through
+                if (level > nd) HIP_TRY(ctx, hipStreamWaitEvent(s2_, ctx->ev_lit[level - nd], 0));
                 intersect(level, s2_, qc, hb, fbm, 2, bb);
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_hit[level], s2_));
                 // the chain of nearest-hit queries is the critical one: its next link is submitted first
@@ -2728,7 +2761,7 @@ extern "C" int rt_render_device_noalloc(rt_ctx *ctx, const rt_render_params *p, 
     mem.limit = RT_SCRATCH_BYTES;
     FrameState fs;
     if (int rc = mem.get(&fs.ctl, 1)) return rc;
-    if (int rc = carve_frame(ctx, mem, fs, slots, cap, (uint32_t)cap, 1, 3)) {
+    if (int rc = carve_frame(ctx, mem, fs, slots, cap, cap, 1.0, 1, 3)) {
         char msg[256];
         snprintf(msg, sizeof(msg), "rt_render_device_noalloc: a frame of %llu pixel slots with %d shadow-casting lights does not fit the %llu MiB static scratch buffer",
                  (unsigned long long)slots, ctx->S.n_shadow_lights, (unsigned long long)(RT_SCRATCH_BYTES >> 20));
@@ -2828,6 +2861,7 @@ extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
         if (!ctx->last_noalloc) ctx->counters_dirty = true;
         if (ctx->last_noalloc) return fail(ctx, RT_ERR_QUEUE_OVERFLOW, "secondary-ray queue overflow in a no-alloc frame (its queues hold 2 x the pixel slots and cannot grow); nothing valid was written");
         if (c.overflow_q && ctx->beam_queue_cap < 0x7fffffffu) ctx->qgrowth *= 8.0;
+        else if (c.overflow_deep && ctx->deep_div > 1.0 && ctx->cap_deep < ctx->cap) ctx->deep_div *= 0.5;
         else ctx->growth *= 2.0;
         return fail(ctx, RT_ERR_QUEUE_OVERFLOW, "secondary-ray queue overflow; queue growth factor doubled, render again");
     }
