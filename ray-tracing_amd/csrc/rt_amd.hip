@@ -1842,7 +1842,6 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
     // gives the same bias without a second queue priority.)
     HIP_C(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
     HIP_C(hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
-    HIP_C(hipStreamCreateWithFlags(&ctx->stream4, hipStreamNonBlocking));
     HIP_C(rt_event_create(&ctx->ev_fork, false));
     HIP_C(rt_event_create(&ctx->ev_join, false));
     ctx->env.read();
@@ -2600,6 +2599,14 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
             // Soft shadows of consecutive levels run side by side (odd levels on stream3, even levels on stream4: each is a latency
             // chain of its own); the Phong terms still reach fb in level order - shade(L) waits for shade(L - 1) - so the
             // float64 sums do not depend on the schedule.
+            // A frame uses four streams, the caller's included - the hardware queues a process has here (GPU_MAX_HW_QUEUES = 4);
+            // a fifth would share a hardware queue with one of the others and wait behind its kernels.  The even levels take
+            // the context's own stream when the caller brought one, else a stream made on first use.
+            hipStream_t s4_ = ctx->stream;
+            if (st == ctx->stream) {
+                if (!ctx->stream4) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream4, hipStreamNonBlocking));
+                s4_ = ctx->stream4;
+            }
             while ((int)ctx->ev_hit.size() <= rec) {
                 hipEvent_t a, b;
                 HIP_TRY(ctx, rt_event_create(&a, false));
@@ -2625,7 +2632,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                 if (level < rec)
                     hipLaunchKernelGGL(k_shade<RT_SHADE_SPAWN>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s2_, ctx->S, lp, qc, qn, hb, ctx->ctl, ctx->fb,
                                        bb.litbits, bb.pair_slot, bb.queue_n);
-                hipStream_t s3_ = (odd || ctx->env.one_shadow_stream) ? ctx->stream3 : ctx->stream4;
+                hipStream_t s3_ = (odd || ctx->env.one_shadow_stream) ? ctx->stream3 : s4_;
                 HIP_TRY(ctx, hipStreamWaitEvent(s3_, ctx->ev_hit[level], 0));
                 if (int rc = shadows(level, s3_, qc, hb, sg, bb, 2)) return rc;
                 if (level >= 2) HIP_TRY(ctx, hipStreamWaitEvent(s3_, ctx->ev_lit[level - 1], 0));
