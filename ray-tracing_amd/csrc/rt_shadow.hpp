@@ -309,11 +309,8 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
             const float blo0 = fminf(m0 * L0, m1 * L0) - E, bhi0 = fmaxf(m0 * U0, m1 * U0) + E;
             const float blo1 = fminf(m0 * L1, m1 * L1) - E, bhi1 = fmaxf(m0 * U1, m1 * U1) + E;
             const float blo2 = fminf(m0 * L2, m1 * L2) - E, bhi2 = fmaxf(m0 * U2, m1 * U2) + E;
-            const uint32_t e_end = nd.a + (nd.b >> 2);
-            LeafF nxt = F.leaves[nd.a];                  // one entry ahead: the loop is bound by memory latency
-            for (uint32_t e = nd.a; e < e_end && nt <= RT_TOUCH && ntu <= RT_CUNITS + 4u; ++e) {   // (leaves at the depth limit hold hundreds of entries)
-                const LeafF lf = nxt;
-                nxt = F.leaves[e + 1u < e_end ? e + 1u : e];
+            // one leaf entry against the beam's part in this leaf; true: a sphere hides the whole light (EARLY), R is final
+            auto entry = [&](const LeafF &lf) -> bool {
                 ++R.trips;
                 const bool sph = !BOXES || (lf.pk & 3u) == 1u;     // sphere {centre, r, (low parts)}; box {lo, -, hi}
                 const float rr = sph ? lf.r : 0.0f;
@@ -346,7 +343,7 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
                                 const float num = fmaf(kt, ta, dp), den = fmaf(-kt, dp, ta);
                                 if (den > 0.0f && fmaf(num, 1.001f, 1e-6f * cn) < tb * den && (Cn + lf.r) * 1.0001f + 1e-4f < smin) {
                                     R.occ_all = true;
-                                    return R;
+                                    return true;
                                 }
                             }
                         }
@@ -362,6 +359,27 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
                             ntu += sph ? 1u : 2u;
                         }
                     }
+                }
+                return false;
+            };
+            const uint32_t e_end = nd.a + (nd.b >> 2);
+            if (!BOXES && !EARLY) {
+                // four entries are requested together: one memory round trip instead of four, four independent tests in flight
+                // (the templates with boxes or the umbra test would spill registers over it)
+                for (uint32_t e0 = nd.a; e0 < e_end && nt <= RT_TOUCH && ntu <= RT_CUNITS + 4u; e0 += 4u) {
+                    LeafF lf4[4];
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) lf4[k4] = F.leaves[min(e0 + (uint32_t)k4, e_end - 1u)];
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4)
+                        if (e0 + (uint32_t)k4 < e_end) (void)entry(lf4[k4]);
+                }
+            } else {
+                LeafF nxt = F.leaves[nd.a];                  // one entry ahead: the loop is bound by memory latency
+                for (uint32_t e = nd.a; e < e_end && nt <= RT_TOUCH && ntu <= RT_CUNITS + 4u; ++e) {   // (leaves at the depth limit hold hundreds of entries)
+                    const LeafF lf = nxt;
+                    nxt = F.leaves[e + 1u < e_end ? e + 1u : e];
+                    if (entry(lf)) return R;
                 }
             }
         }
@@ -381,12 +399,13 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
         const DPrim *pr = S.prims + tl[k * STRIDE];
         const uint32_t kind = BOXES ? (uint32_t)pr->kind : 1u;
         const bool sph = !BOXES || kind == 1u;
+        const double pa0 = pr->a[0], pa1 = pr->a[1], pa2 = pr->a[2], pb0 = pr->b[0], pb1 = pr->b[1];
         double dx = 0, dy = 0, dz = 0, cd = 0;
         float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, lfr = 0.0f;
         if (sph) {
-            dx = pr->a[0] - P.x; dy = pr->a[1] - P.y; dz = pr->a[2] - P.z;
+            dx = pa0 - P.x; dy = pa1 - P.y; dz = pa2 - P.z;
             c0 = (float)dx; c1 = (float)dy; c2 = (float)dz;
-            lfr = __double2float_ru(fabs(pr->b[1]));           // radius, rounded up like the leaf record's
+            lfr = __double2float_ru(fabs(pb1));           // radius, rounded up like the leaf record's
         }
         float ta = 0.0f, dp2 = 0.0f, cn = 0.0f;
         if (sph && cone_ok) {                        // (passed the cone test in phase 1)
@@ -397,7 +416,7 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
         }
         bool store = true;
         if (sph) {
-            cd = ((dx * dx + dy * dy) + dz * dz) - pr->b[0];
+            cd = ((dx * dx + dy * dy) + dz * dz) - pb0;
             if (cone_ok) {                       // whole-pair verdict (see above)
                 // Every ray of the pair misses the sphere?  At the centre's axial depth ta the rays cross the
                 // rectangle |x|, |y| <= aq t, t <= ta / (|cB| - ja); a line at angle phi to the axis stays
