@@ -81,14 +81,19 @@ def algorithmic_flops(cnt, n_lights, n_planes):
     return frame, shadow
 
 
+PMC_FRAME_HITS = {"synth10k_1920x1080": 2187093}      # shaded hits (all levels) of the frame the counter passes ran on
+
+
 def profile_file(workload, W, H, world):
-    """committed hardware-counter summary of this workload (None when there is none for this shape)"""
-    name = {"synth10k": "synth10k_1920x1080"}.get(workload) if (W, H, world) == (1920, 1080, 1) else None
+    """committed hardware-counter summary of this workload -> (summary, path, hits of the profiled frame).  The counters were
+    collected on the 1920x1080 frame; for another shape of the same scene (a rank's share of 3840x2160) the executed work is
+    scaled by the number of (hit, light) pairs, which is what the kernel's work is proportional to (same scene, same camera)."""
+    name = {"synth10k": "synth10k_1920x1080"}.get(workload)
     path = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % name) if name else None
     if path and os.path.exists(path):
         with open(path) as f:
-            return json.load(f), os.path.relpath(path, ROOT)
-    return None, None
+            return json.load(f), os.path.relpath(path, ROOT), PMC_FRAME_HITS[name]
+    return None, None, None
 
 
 def time_frames(ctx, abi, native, torch, stream, W, H, frames, warm, **kw):
@@ -331,15 +336,18 @@ def main():
         # side), so their durations add up to more than the kernel's own time; they are printed beside it.
         ms_kernel = prof["ms_beam_setup"]
         launches = prof["beam_setup_launches"] or live_launches
-        pmc, pmc_path = profile_file(args.workload, W, H, world)
+        pmc, pmc_path, pmc_hits = profile_file(args.workload, W, H, world)
         kname = next((k for k in (pmc["kernels"] if pmc else {}) if k.startswith("k_beam_setup")), None)
-        executed = pmc["kernels"][kname]["executed_flop_per_frame"] if kname else None
+        same_shape = (W, H, world) == (1920, 1080, 1) and args.sh_rays is None and args.rec_max is None
+        pair_scale = 1.0 if same_shape else (prof["hits"] / float(pmc_hits) if pmc_hits else None)
+        executed = pmc["kernels"][kname]["executed_flop_per_frame"] * pair_scale if (kname and pair_scale) else None
         achieved = executed / (ms_kernel * 1e-3) / 1e12 if (executed and ms_kernel > 0) else None
         roofline = {
             "bound": "valu", "kernel": kname or "k_beam_setup",
             "achieved": round(achieved, 3) if achieved is not None else None, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4) if achieved is not None else None,
-            "traffic": pmc["kernels"][kname].get("hbm_bytes_per_frame") if kname else None,
+            "traffic": (pmc["kernels"][kname].get("hbm_bytes_per_frame") or 0) * pair_scale if (kname and pair_scale) else None,
+            "executed_work_scaled_by_pairs": None if same_shape else pair_scale,
             "traffic_unit": "HBM-side bytes of the kernel's launches of one frame (2 x FETCH_SIZE + WRITE_SIZE)",
             "achieved_is": "floating-point operations the kernel EXECUTES per frame (hardware counters: ADD + MUL + TRANS + 2 FMA, "
                            "float32 and float64, x active lanes; %s, tree %s) / its launches' duration measured in this run "
