@@ -1666,12 +1666,6 @@ struct rt_ctx : FrameState {
     rt_render_params last{};
     int32_t last_sh = 0, last_rec = 0;
     uint64_t last_slots = 0;
-    // rays of overflowing pairs per level in the last frame whose counters were read (rt_sync_stats), and that frame's shape:
-    // a level that had fewer than walk_min of them is not given a k_shadow_walk launch in the next frame of the same shape
-    // (k_shadow_queue takes such rays itself; the same verdicts either way, one latency-bound launch less per level)
-    uint32_t seen_walk[RT_MAX_LEVELS + 2] = {0};
-    uint64_t seen_slots = 0;
-    int32_t seen_sh = 0, seen_rec = -2;
     bool last_gen = false;      // the last frame enqueued was a camera frame (rt_render_device), not an rt_trace batch
     int grid = 2048;
     int n_cu = 256;
@@ -2449,7 +2443,6 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         lp.cap = (uint32_t)(level == 0 ? ctx->cap : ctx->cap_deep);
     };
     lp.unit_thr = gen ? 1 : 0;
-    const uint64_t frame_slots = gen ? ctx->fb_slots_frame : ~0ull;     // (shape of the frame, for rt_ctx::seen_walk)
     {
         // k_shadow_walk pays when a level has millions of rays in overflowing pairs (1 M lattice: 17 M); with few of them
         // a second latency-bound kernel only adds its tail.  RT_AMD_WALK_MIN: 1 = always, -1 = never (diagnostic).
@@ -2507,11 +2500,12 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                 if (time_bs) { HIP_TRY(ctx, hipEventRecord(ctx->prof_bs[2 * level + 1], s_)); ctx->prof_bs_levels = level + 1; }
             }
             hipLaunchKernelGGL(k_shadow_beam, dim3(gsz(ctx->g_beam, ctx->nb_beam, side == 1 ? 3 : side)), block, 0, s_, ctx->S, lp, hb, bb, ctx->ctl);
-            // k_shadow_walk only where the last frame of this shape had work for it (rt_ctx::seen_walk); without the launch
-            // k_shadow_queue is told that there is no walk (walk_min = never) and expands the overflowing pairs itself
-            const bool known = ctx->seen_rec == rec && ctx->seen_sh == sh && ctx->seen_slots == frame_slots && level <= RT_MAX_LEVELS;
+            // k_shadow_walk is launched for scenes of >= 100 k primitives only (where a level can hold millions of rays of
+            // overflowing pairs; RT_AMD_WALK_MIN = 1 forces it): a rule of the scene, not of earlier frames.  Without the launch
+            // k_shadow_queue is told that there is no walk (walk_min = never) and expands the overflowing pairs itself - the
+            // same verdicts, one latency-bound launch less per level.
             LevelParams lq = lp;
-            if (known && ctx->seen_walk[level] < lp.walk_min) lq.walk_min = 0xffffffffu;
+            if (ctx->S.n_prims < 100000 && ctx->env.walk_min != 1) lq.walk_min = 0xffffffffu;
             if (lq.walk_min != 0xffffffffu)
                 hipLaunchKernelGGL(k_shadow_walk, dim3(gsz(ctx->g_walk, ctx->nb_walk, side == 1 ? 3 : side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lq, hb, bb, ctx->ctl);
             hipLaunchKernelGGL(k_shadow_queue, dim3(gsz(ctx->g_queue, ctx->nb_queue, side == 1 ? 3 : side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lq, qc, hb, sg, bb, ctx->ctl);
@@ -2792,10 +2786,6 @@ extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
     ctx->frame_pending = false;
     const FrameCtl &c = *ctx->h_ctl;
-    if (!c.overflow) {
-        for (int l = 0; l < RT_MAX_LEVELS + 2; ++l) ctx->seen_walk[l] = c.n_walked[l];
-        ctx->seen_slots = ctx->last_gen ? ctx->last_slots : 0; ctx->seen_sh = ctx->last_sh; ctx->seen_rec = ctx->last_rec;
-    }
     if (stats) {
         memset(stats, 0, sizeof(*stats));
         stats->primary_rays = (int64_t)c.primary_rays;
