@@ -268,6 +268,9 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
     clip_mul(l0, l1, -U1, -iU1, -((F.root_lo[1] - Pf1) - E)); clip_mul(l0, l1, L1, iL1, (F.root_hi[1] - Pf1) + E);
     clip_mul(l0, l1, -U2, -iU2, -((F.root_lo[2] - Pf2) - E)); clip_mul(l0, l1, L2, iL2, (F.root_hi[2] - Pf2) + E);
     if (!(l0 <= l1)) return R;
+    // The light's sample box is wider than it is far (a light of radius 10 inside a scene of extent 4: original.txt): the beam is
+    // no beam, it meets everything near P - its rays are decided one by one, the walk below would only end in an overflow.
+    if (rho2 > 1.0f) { R.overflow = true; R.why = 1; return R; }
 
     // ---- phase 1: traversal.  The loops carry only the traversal state; a leaf entry that passes the float32
     // tests is parked (its primitive number, once) in the lane's LDS list tl[] (RT_TOUCH entries) and looked at
