@@ -143,6 +143,8 @@ typedef struct rt_render_params {
                                       s*s <= 4) take the general wavefront pipeline instead; same result */
 #define RT_FLAG_TIME_DOMINANT 32   /* HIP events around the k_beam_setup launches only, schedule unchanged (levels stay overlapped):
                                       rt_stats.ms_beam_setup / beam_setup_launches of that frame (bench.py: live duration of the dominant kernel) */
+#define RT_FLAG_NO_TILES 64        /* diagnostic: every (hit, light) pair of level 0 walks the tree itself instead of filtering the
+                                      candidate row that the binning kernels made for its 8 x 8 pixel tile; same result */
 #define RT_FLAG_PROFILE 2          /* bracket every kernel launch with HIP events on the launch stream and
                                       report per-family device time in rt_stats (used by bench.py's roofline) */
 
@@ -234,6 +236,8 @@ int rt_render_device_noalloc(rt_ctx *ctx, const rt_render_params *p, float *d_rg
 int64_t rt_noalloc_scratch_bytes(void);
 /* Diagnostic: number of allocating HIP calls (hipMalloc, hipHostMalloc, event creation) this library has issued in the process. */
 int64_t rt_debug_alloc_calls(void);
+/* Diagnostic: frames this context has enqueued with tile beams (candidates per 8 x 8 pixel tile by binning, see RT_FLAG_NO_TILES). */
+int64_t rt_debug_tile_frames(const rt_ctx *ctx);
 
 /*
  * Replaces ray_tracing(rays_sources, rays_directions, ...) (ray_tracer.py:36-133)

@@ -11,6 +11,7 @@ RT_FLAG_NO_BEAM = 4
 RT_FLAG_NO_OVERLAP = 8
 RT_FLAG_NO_SMALL = 16
 RT_FLAG_TIME_DOMINANT = 32
+RT_FLAG_NO_TILES = 64
 
 RT_OK = 0
 RT_ERR_INVALID_ARG, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_OOM, RT_ERR_QUEUE_OVERFLOW, RT_ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6

@@ -64,6 +64,8 @@ struct FrameCtl {
     uint32_t n_walked[RT_MAX_LEVELS + 2];   // rays of overflowing pairs (k_shadow_walk)
     uint32_t dbg_max_trips, dbg_pad;        // RT_FLAG 0x1000: longest / total beam traversal of the frame
     uint32_t dbg_why[4];                    // pairs sent to the queue: delicate basis, touched list, units, dedup list
+    unsigned long long dbg_tcyc[4];
+    uint32_t dbg_tile[8];                   // flag 0x1000, tile beams: (zone, light) rows / entries, (region, light) rows / entries / overflows, (block, light) rows / entries / overflows
     unsigned long long dbg_sum_trips;
 };
 
@@ -107,7 +109,139 @@ struct LevelParams {
     int32_t beam_early;                  // beam traversal near side first with the umbra test inside it (scenes with long beams)
     uint32_t walk_min;                   // rays of overflowing pairs: k_shadow_walk takes them when a level has at least this
                                          // many, else k_shadow_queue expands them (same verdicts either way)
+    int32_t tiles;                       // tile beams: the k_bin_* kernels have listed this level's candidates per (block, light)
+    uint32_t tile_stride;                // blocks per image row of blocks at level 0 of a camera frame (regions are squares), else 0
 };
+
+// ------------------------------------------------------------------------------------------------
+// tile beams: block / region / zone geometry and the union beam of a group of hit points towards a light
+// ------------------------------------------------------------------------------------------------
+// half size of the box around a light's position that holds every sample origin of Light.get_shadow_rays for any shaded
+// point: |coefficient of up|, |coefficient of right| <= (radius + g) / 2 with the deviations of Light.py:277-279, and
+// |up_k| + |right_k| <= 2.  The binning kernels build the base box of a union beam from it, k_beam_setup checks its own
+// sample box against it (same expression in both).
+__device__ __forceinline__ float tile_light_half(float radius, float g) { return (radius + g) * 1.001f + 1e-5f; }
+#define RT_2M17 7.6293945e-06f
+
+struct TileGrid {                       // blocks of 64 ray slots -> regions of 4 x 4 blocks -> zones of 8 x 8 regions
+    uint32_t nblk, ts, rpr, nreg, zpr, nzone;
+    enum : uint32_t { rxs = 2u, rys = 2u };
+    // stride: blocks per image row of blocks (0: no image structure, blocks in sequence)
+    __host__ __device__ TileGrid(uint32_t n_rays, uint32_t stride) {
+        nblk = (n_rays + 63u) >> 6;
+        ts = stride;
+        if (ts) {
+            const uint32_t rrows = (((nblk + ts - 1u) / ts) + (1u << rys) - 1u) >> rys;
+            rpr = (ts + (1u << rxs) - 1u) >> rxs; nreg = rpr * rrows;
+            zpr = (rpr + 7u) >> 3; nzone = zpr * ((rrows + 7u) >> 3);
+        } else { rpr = 0u; zpr = 0u; nreg = (nblk + RT_REGION_BLOCKS - 1u) / RT_REGION_BLOCKS; nzone = (nreg + 63u) >> 6; }
+    }
+    __device__ uint32_t region_of(uint32_t blk) const {
+        if (!ts) return blk / RT_REGION_BLOCKS;
+        const uint32_t by = blk / ts, bx = blk - by * ts;
+        return (by >> rys) * rpr + (bx >> rxs);
+    }
+    // block j (0..15) of region r, or 0xffffffff
+    __device__ uint32_t block_of(uint32_t r, uint32_t j) const {
+        uint32_t blk;
+        if (!ts) blk = r * RT_REGION_BLOCKS + j;
+        else {
+            const uint32_t ry = r / rpr, rx = r - ry * rpr, bx = (rx << rxs) + (j & ((1u << rxs) - 1u)), by = (ry << rys) + (j >> rxs);
+            if (bx >= ts) return 0xffffffffu;
+            blk = by * ts + bx;
+        }
+        return blk < nblk ? blk : 0xffffffffu;
+    }
+    __device__ uint32_t zone_of(uint32_t r) const {
+        if (!ts) return r >> 6;
+        const uint32_t ry = r / rpr, rx = r - ry * rpr;
+        return (ry >> 3) * zpr + (rx >> 3);
+    }
+    // region j (0..63) of zone z, or 0xffffffff
+    __device__ uint32_t region_in(uint32_t z, uint32_t j) const {
+        uint32_t r;
+        if (!ts) r = z * 64u + j;
+        else {
+            const uint32_t zy = z / zpr, zx = z - zy * zpr, rx = zx * 8u + (j & 7u), ry = zy * 8u + (j >> 3);
+            if (rx >= rpr) return 0xffffffffu;
+            r = ry * rpr + rx;
+        }
+        return r < nreg ? r : 0xffffffffu;
+    }
+};
+
+// Union of the beams of every shaded point in the box [pl, ph] towards one light: the points (1 - lambda) p + lambda s, p in
+// the box, s in the box [sl, sh] of the light's sample origins; per axis k they lie in [pl_k + lambda L_k, ph_k + lambda U_k]
+// (L = sl - pl, U = sh - ph) - linear in lambda like a single beam, so the interval clipping of beam_collect applies with the
+// apex taken on the side that is tested.  [l0, l1]: the part inside the tree's root box; [alo, ahi]: its bounding box.
+struct UBeam {
+    float pl0, pl1, pl2, ph0, ph1, ph2, L0, L1, L2, U0, U1, U2, iL0, iL1, iL2, iU0, iU1, iU2, E, l0, l1;
+    float alo0, alo1, alo2, ahi0, ahi1, ahi2;
+    bool ok;                            // false: no hit point, or the union misses the root box
+    bool wild;                          // coordinates outside the float32 filters' range: no list (the pairs are delicate anyway)
+};
+struct ULight { float c0, c1, c2, radius; };       // a shadow light as the binning kernels need it (loaded once per row)
+__device__ __forceinline__ ULight ulight_load(const DScene &S, uint32_t ml) {
+    const DLight &Lt = S.lights[S.shadow_lights[ml]];
+    ULight u;
+    u.c0 = (float)Lt.pos[0]; u.c1 = (float)Lt.pos[1]; u.c2 = (float)Lt.pos[2]; u.radius = (float)Lt.radius;
+    return u;
+}
+__device__ __forceinline__ UBeam ubeam_make(const ULight &Lt, const FastScene &F, float4 lo, float4 hi, int sh_rays) {
+    UBeam B;
+    B.ok = lo.x <= hi.x;
+    const float radius = Lt.radius, g = radius / (float)sh_rays;
+    const float Rs = tile_light_half(radius, g);
+    const float c0 = Lt.c0, c1 = Lt.c1, c2 = Lt.c2;
+    // + what the pairs' own float32 arithmetic can add (their sample boxes carry 2^-18 relative slack)
+    const float k0 = fmaxf(fabsf(lo.x), fabsf(hi.x)), k1 = fmaxf(fabsf(lo.y), fabsf(hi.y)), k2 = fmaxf(fabsf(lo.z), fabsf(hi.z));
+    const float r0 = Rs + RT_2M17 * (fmaxf(fabsf(c0 - lo.x), fabsf(c0 - hi.x)) + Rs + fabsf(c0) + k0) + 2e-5f;
+    const float r1 = Rs + RT_2M17 * (fmaxf(fabsf(c1 - lo.y), fabsf(c1 - hi.y)) + Rs + fabsf(c1) + k1) + 2e-5f;
+    const float r2 = Rs + RT_2M17 * (fmaxf(fabsf(c2 - lo.z), fabsf(c2 - hi.z)) + Rs + fabsf(c2) + k2) + 2e-5f;
+    B.wild = !(fmaxf(fmaxf(k0, k1), k2) < 1e7f) || !(fmaxf(fmaxf(fabsf(c0), fabsf(c1)), fabsf(c2)) < 1e7f);
+    B.pl0 = lo.x; B.pl1 = lo.y; B.pl2 = lo.z; B.ph0 = hi.x; B.ph1 = hi.y; B.ph2 = hi.z;
+    const float Kp = fmaxf(fmaxf(k0, k1), fmaxf(k2, F.extent));
+    B.E = Kp * RT_2M19 + 2e-6f;          // absolute slack on every plane position, as in beam_collect
+    B.L0 = (c0 - r0) - lo.x; B.L1 = (c1 - r1) - lo.y; B.L2 = (c2 - r2) - lo.z;
+    B.U0 = (c0 + r0) - hi.x; B.U1 = (c1 + r1) - hi.y; B.U2 = (c2 + r2) - hi.z;
+    B.iL0 = __builtin_amdgcn_rcpf(B.L0); B.iL1 = __builtin_amdgcn_rcpf(B.L1); B.iL2 = __builtin_amdgcn_rcpf(B.L2);
+    B.iU0 = __builtin_amdgcn_rcpf(B.U0); B.iU1 = __builtin_amdgcn_rcpf(B.U1); B.iU2 = __builtin_amdgcn_rcpf(B.U2);
+    float l0 = 0.0f, l1 = 1.0f;
+    const float E = B.E;
+    clip_mul(l0, l1, -B.U0, -B.iU0, -((F.root_lo[0] - B.ph0) - E)); clip_mul(l0, l1, B.L0, B.iL0, (F.root_hi[0] - B.pl0) + E);
+    clip_mul(l0, l1, -B.U1, -B.iU1, -((F.root_lo[1] - B.ph1) - E)); clip_mul(l0, l1, B.L1, B.iL1, (F.root_hi[1] - B.pl1) + E);
+    clip_mul(l0, l1, -B.U2, -B.iU2, -((F.root_lo[2] - B.ph2) - E)); clip_mul(l0, l1, B.L2, B.iL2, (F.root_hi[2] - B.pl2) + E);
+    B.ok = B.ok && l0 <= l1;
+    B.l0 = fmaxf(l0 - 1e-6f, 0.0f); B.l1 = fminf(l1 + 1e-6f, 1.0f);
+    B.alo0 = B.pl0 + fminf(B.l0 * B.L0, B.l1 * B.L0) - E; B.ahi0 = B.ph0 + fmaxf(B.l0 * B.U0, B.l1 * B.U0) + E;
+    B.alo1 = B.pl1 + fminf(B.l0 * B.L1, B.l1 * B.L1) - E; B.ahi1 = B.ph1 + fmaxf(B.l0 * B.U1, B.l1 * B.U1) + E;
+    B.alo2 = B.pl2 + fminf(B.l0 * B.L2, B.l1 * B.L2) - E; B.ahi2 = B.ph2 + fmaxf(B.l0 * B.U2, B.l1 * B.U2) + E;
+    return B;
+}
+// bounding box of a leaf record (sphere {centre, r}; box {lo, -, hi})
+__device__ __forceinline__ void leaf_box(const LeafF &lf, float &e0, float &e1, float &e2, float &f0, float &f1, float &f2) {
+    const bool sph = (lf.pk & 3u) == 1u;
+    const float rr = sph ? lf.r : 0.0f;
+    e0 = lf.x - rr; e1 = lf.y - rr; e2 = lf.z - rr;
+    f0 = sph ? lf.x + rr : lf.lx; f1 = sph ? lf.y + rr : lf.ly; f2 = sph ? lf.z + rr : lf.lz;
+}
+// the primitive's box against the bounding box of the union's part inside the root box (zones, regions)
+__device__ __forceinline__ bool ubeam_near(const UBeam &B, const LeafF &lf) {
+    float e0, e1, e2, f0, f1, f2;
+    leaf_box(lf, e0, e1, e2, f0, f1, f2);
+    return !(e0 > B.ahi0) && !(f0 < B.alo0) && !(e1 > B.ahi1) && !(f1 < B.alo1) && !(e2 > B.ahi2) && !(f2 < B.alo2);
+}
+// ... against the moving box itself: some lambda of [l0, l1] at which the two boxes meet (blocks)
+__device__ __forceinline__ bool ubeam_touch(const UBeam &B, const LeafF &lf) {
+    float e0, e1, e2, f0, f1, f2;
+    leaf_box(lf, e0, e1, e2, f0, f1, f2);
+    const float E = B.E;
+    float x0 = B.l0, x1 = B.l1, y0 = B.l0, y1 = B.l1, z0 = B.l0, z1 = B.l1;       // three independent per-axis intervals
+    clip_mul(x0, x1, B.L0, B.iL0, (f0 - B.pl0) + E); clip_mul(x0, x1, -B.U0, -B.iU0, -((e0 - B.ph0) - E));
+    clip_mul(y0, y1, B.L1, B.iL1, (f1 - B.pl1) + E); clip_mul(y0, y1, -B.U1, -B.iU1, -((e1 - B.ph1) - E));
+    clip_mul(z0, z1, B.L2, B.iL2, (f2 - B.pl2) + E); clip_mul(z0, z1, -B.U2, -B.iU2, -((e2 - B.ph2) - E));
+    return fmaxf(fmaxf(x0, y0), z0) <= fminf(fminf(x1, y1), z1) && x0 <= x1 && y0 <= y1 && z0 <= z1;
+}
 
 // XCD-aware chunk walk.  A chunk is RT_BLOCK consecutive items; chunks are dealt to the 8 XCDs in groups of
 // RT_XCD_GROUP (group g -> XCD g % 8; workgroups b and b+8 share an XCD and its L2): items that are neighbours in
@@ -348,6 +482,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                 has_hit = true;
             }
         }
+        if (!has_hit && k < n) hb.id[k] = 0;      // (k_block_box reads the hit record of every slot)
         // Compaction of the hit list.  The hits of a wave are parked in its LDS buffer and leave RT_HIT_RUN at a time: ONE
         // returning atomic on the list counter per run.  (One per wave and chunk - 32 400 of them in a 1920x1080
         // camera-ray pass, all on one address, ~12 ns each - was what the pass took, whatever the scene: 0.40 ms.)
@@ -479,6 +614,239 @@ __device__ __forceinline__ void wave_append_flush(T *buf, uint32_t n, uint32_t *
     if ((uint32_t)lane < n) store(base + (uint32_t)lane, buf[lane]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// tile beams: candidates per (block, light) by binning - zone -> region -> block, no tree walk, no long dependent chains
+// ------------------------------------------------------------------------------------------------
+// The pairs of a block of 64 ray slots (an 8x8 pixel tile at level 0) send nearly the same beam towards a light.  Every
+// primitive is tested against the union beam of a ZONE (64 regions) and listed there; a REGION (4 x 4 blocks) keeps what of
+// its zone's list its own union beam can touch, a BLOCK what of its region's list it can touch (exact test against the moving
+// box) - at most RT_TILE_NC leaf records per (block, light), which k_beam_setup<.., true> filters per pair instead of walking
+// the tree.  All passes are flat data-parallel loops.
+
+// box of the hit points of every block (one wave per block), rounded outward; the zones' list counters are cleared on the way
+__global__ void __launch_bounds__(RT_BLOCK) k_block_box(DScene S, LevelParams lp, HitBuf hb, BeamBuf bb, FrameCtl *ctl) {
+    if (ctl->overflow) return;
+    const uint32_t n = min(ctl->n_rays[lp.level], lp.cap);
+    const TileGrid G(n, lp.tile_stride);
+    const uint32_t zrows = G.nzone * (uint32_t)S.n_shadow_lights;
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < zrows; i += gridDim.x * RT_BLOCK) bb.zcnt[i] = 0u;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t k0 = (uint64_t)blockIdx.x * RT_BLOCK; k0 < n; k0 += (uint64_t)gridDim.x * RT_BLOCK) {
+        const uint64_t k = k0 + threadIdx.x;
+        const uint64_t kk = k < n ? k : (uint64_t)(n - 1u);       // (coordinates of a miss: whatever the buffers hold, not used)
+        const double x = hb.px[kk], y = hb.py[kk], z = hb.pz[kk];
+        const bool has_hit = k < n && hb.id[kk] != 0;
+        const float inf = __int_as_float(0x7f800000);
+        float b0 = inf, b1 = inf, b2 = inf, B0 = -inf, B1 = -inf, B2 = -inf;
+        if (has_hit) {
+            b0 = __double2float_rd(x); b1 = __double2float_rd(y); b2 = __double2float_rd(z);
+            B0 = __double2float_ru(x); B1 = __double2float_ru(y); B2 = __double2float_ru(z);
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            b0 = fminf(b0, __shfl_xor(b0, off)); b1 = fminf(b1, __shfl_xor(b1, off)); b2 = fminf(b2, __shfl_xor(b2, off));
+            B0 = fmaxf(B0, __shfl_xor(B0, off)); B1 = fmaxf(B1, __shfl_xor(B1, off)); B2 = fmaxf(B2, __shfl_xor(B2, off));
+        }
+        if (lane == 0 && k < n) {
+            float4 *bx = (float4 *)(bb.blockbox + 8ull * (k >> 6));
+            bx[0] = make_float4(b0, b1, b2, 0.0f);
+            bx[1] = make_float4(B0, B1, B2, 0.0f);
+        }
+    }
+}
+
+// union of the boxes of blocks [first, first + count) given by index function f (lane-strided), reduced over the wave
+template <typename Fn>
+__device__ __forceinline__ void wave_union_box(const float *blockbox, uint32_t count, Fn block_at, int lane, float4 &lo, float4 &hi,
+                                               float4 *mylo = nullptr, float4 *myhi = nullptr) {
+    const float inf = __int_as_float(0x7f800000);
+    float b0 = inf, b1 = inf, b2 = inf, B0 = -inf, B1 = -inf, B2 = -inf;
+    for (uint32_t j = (uint32_t)lane; j < count; j += 64u) {
+        const uint32_t blk = block_at(j);
+        if (blk == 0xffffffffu) continue;
+        const float4 l = ((const float4 *)(blockbox + 8ull * blk))[0], h = ((const float4 *)(blockbox + 8ull * blk))[1];
+        if (mylo) { *mylo = l; *myhi = h; }      // (count <= 64: the lane's one box)
+        if (!(l.x <= h.x)) continue;
+        b0 = fminf(b0, l.x); b1 = fminf(b1, l.y); b2 = fminf(b2, l.z);
+        B0 = fmaxf(B0, h.x); B1 = fmaxf(B1, h.y); B2 = fmaxf(B2, h.z);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        b0 = fminf(b0, __shfl_xor(b0, off)); b1 = fminf(b1, __shfl_xor(b1, off)); b2 = fminf(b2, __shfl_xor(b2, off));
+        B0 = fmaxf(B0, __shfl_xor(B0, off)); B1 = fmaxf(B1, __shfl_xor(B1, off)); B2 = fmaxf(B2, __shfl_xor(B2, off));
+    }
+    lo = make_float4(b0, b1, b2, 0.0f); hi = make_float4(B0, B1, B2, 0.0f);
+}
+
+// zones: every primitive against the union beam of each (zone, light); work item = (row, group of 8 chunks of RT_BLOCK primitives)
+__global__ void __launch_bounds__(RT_BLOCK) k_bin_zone(DScene S, FastScene F, LevelParams lp, BeamBuf bb, FrameCtl *ctl) {
+    if (ctl->overflow) return;
+    const uint32_t n = min(ctl->n_rays[lp.level], lp.cap);
+    const TileGrid G(n, lp.tile_stride);
+    const uint32_t nsl = (uint32_t)S.n_shadow_lights, np = (uint32_t)S.n_prims, zcap = min(np, RT_ZONE_NC);
+    const uint32_t ngroup = (np + 8u * RT_BLOCK - 1u) / (8u * RT_BLOCK), items = G.nzone * nsl * ngroup;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float4 zbox[2 * (RT_BLOCK / 64)];
+    for (uint32_t it = blockIdx.x; it < items; it += gridDim.x) {
+        const uint32_t row = it / ngroup, group = it - row * ngroup;
+        const uint32_t zone = row / nsl, ml = row - zone * nsl;
+        // the zone's box: 1024 block boxes, 256 per wave (4 per lane), combined through LDS
+        float4 lo, hi;
+        wave_union_box(bb.blockbox, 256u, [&](uint32_t jj) {
+            const uint32_t j = (uint32_t)wave * 256u + jj, r = G.region_in(zone, j >> 4);
+            return r != 0xffffffffu ? G.block_of(r, j & 15u) : 0xffffffffu; }, lane, lo, hi);
+        __syncthreads();
+        if (lane == 0) { zbox[2 * wave] = lo; zbox[2 * wave + 1] = hi; }
+        __syncthreads();
+        for (int w = 0; w < RT_BLOCK / 64; ++w) {
+            const float4 l = zbox[2 * w], h = zbox[2 * w + 1];
+            lo.x = fminf(lo.x, l.x); lo.y = fminf(lo.y, l.y); lo.z = fminf(lo.z, l.z);
+            hi.x = fmaxf(hi.x, h.x); hi.y = fmaxf(hi.y, h.y); hi.z = fmaxf(hi.z, h.z);
+        }
+        const UBeam B = ubeam_make(ulight_load(S, ml), F, lo, hi, lp.sh_rays);
+        if (!B.ok) continue;
+        // (all loads of the group's 8 chunks are in flight together; one returning atomic per wave)
+        uint32_t ce[8];
+        LeafF lf[8];
+#pragma unroll
+        for (uint32_t c = 0; c < 8u; ++c) {
+            const uint32_t p = (group * 8u + c) * RT_BLOCK + threadIdx.x;
+            ce[c] = p < np ? F.prim_entry[p] : 0u;
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < 8u; ++c) lf[c] = F.leaves[ce[c]];
+        uint32_t keepm = 0u, total = 0u, pos_of[8];
+#pragma unroll
+        for (uint32_t c = 0; c < 8u; ++c) {
+            const uint32_t p = (group * 8u + c) * RT_BLOCK + threadIdx.x;
+            const bool keep = p < np && (B.wild || ubeam_near(B, lf[c]));
+            const unsigned long long m = __ballot(keep);
+            if (keep) keepm |= 1u << c;
+            pos_of[c] = total + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            total += (uint32_t)__popcll(m);
+        }
+        if (total) {
+            uint32_t base = 0u;
+            if (lane == 0) base = atomicAdd(&bb.zcnt[row], total);
+            base = __shfl(base, 0);
+#pragma unroll
+            for (uint32_t c = 0; c < 8u; ++c)
+                if (((keepm >> c) & 1u) && base + pos_of[c] < zcap) bb.zlist[(uint64_t)row * zcap + base + pos_of[c]] = ce[c];
+        }
+    }
+}
+
+// regions and blocks: one workgroup per (region, light) keeps what of its zone's list the region's union beam comes near - as
+// leaf records, in LDS -, then each wave filters that for 4 of the region's 16 blocks (exact test against the block's moving
+// box) and writes the blocks' candidate rows
+__global__ void __launch_bounds__(RT_BLOCK) k_bin_tiles(DScene S, FastScene F, LevelParams lp, BeamBuf bb, FrameCtl *ctl) {
+    __shared__ uint32_t cnt;
+    __shared__ float4 recs[2 * RT_REGION_NC];
+    if (ctl->overflow) return;
+    const uint32_t n = min(ctl->n_rays[lp.level], lp.cap);
+    const TileGrid G(n, lp.tile_stride);
+    const uint32_t nsl = (uint32_t)S.n_shadow_lights, zcap = min((uint32_t)S.n_prims, RT_ZONE_NC), rows = G.nreg * nsl;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const long long tc0 = wall_clock64();
+        const uint32_t reg = row / nsl, ml = row - reg * nsl;
+        // the zone's list: its length and the lane's first two entries are requested before anything else of the row
+        const uint32_t zrow = G.zone_of(reg) * nsl + ml;
+        const uint32_t *zl = bb.zlist + (uint64_t)zrow * zcap;
+        const uint32_t zc = bb.zcnt[zrow], zn = min(zc, zcap);
+        uint32_t ce_a = threadIdx.x < zcap ? zl[threadIdx.x] : 0u, ce_b = threadIdx.x + RT_BLOCK < zcap ? zl[threadIdx.x + RT_BLOCK] : 0u;
+        float4 lo, hi;
+        const float inf = __int_as_float(0x7f800000);
+        float4 mylo = make_float4(inf, inf, inf, 0.0f), myhi = make_float4(-inf, -inf, -inf, 0.0f);
+        wave_union_box(bb.blockbox, RT_REGION_BLOCKS, [&](uint32_t j) { return G.block_of(reg, j); }, lane, lo, hi, &mylo, &myhi);
+        const ULight UL = ulight_load(S, ml);
+        const UBeam B = ubeam_make(UL, F, lo, hi, lp.sh_rays);
+        __syncthreads();                 // (the last readers of the counter and of the records are through)
+        if (threadIdx.x == 0) cnt = 0u;
+        __syncthreads();
+        const long long tc1 = wall_clock64();
+        bool over = B.ok && (zc > zcap || B.wild);
+        if (B.ok && !over) {
+            for (uint32_t i0 = 0; i0 < zn; i0 += 2u * RT_BLOCK) {
+                const uint32_t ia = i0 + threadIdx.x, ib = ia + RT_BLOCK;
+                if (i0) { ce_a = ia < zn ? zl[ia] : 0u; ce_b = ib < zn ? zl[ib] : 0u; }
+                const LeafF la = F.leaves[ia < zn ? ce_a : 0u], lb = F.leaves[ib < zn ? ce_b : 0u];
+                const bool ka = ia < zn && ubeam_near(B, la), kb = ib < zn && ubeam_near(B, lb);
+                const unsigned long long ma = __ballot(ka), mb = __ballot(kb);
+                if (ma | mb) {
+                    uint32_t base = 0u;
+                    if (lane == 0) base = atomicAdd(&cnt, (uint32_t)(__popcll(ma) + __popcll(mb)));
+                    base = __shfl(base, 0);
+                    const uint32_t pa = base + (uint32_t)__popcll(ma & ((1ull << lane) - 1ull));
+                    const uint32_t pb = base + (uint32_t)__popcll(ma) + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
+                    if (ka && pa < RT_REGION_NC) {
+                        recs[2u * pa] = make_float4(la.x, la.y, la.z, la.r);
+                        recs[2u * pa + 1u] = make_float4(la.lx, la.ly, la.lz, __uint_as_float(la.pk));
+                    }
+                    if (kb && pb < RT_REGION_NC) {
+                        recs[2u * pb] = make_float4(lb.x, lb.y, lb.z, lb.r);
+                        recs[2u * pb + 1u] = make_float4(lb.lx, lb.ly, lb.lz, __uint_as_float(lb.pk));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const long long tc2 = wall_clock64();
+        const uint32_t rn = cnt;
+        over = over || rn > RT_REGION_NC;
+        if ((lp.flags & 0x1000) && threadIdx.x == 0 && B.ok) {
+            atomicAdd(&ctl->dbg_tile[1], zn);
+            atomicAdd(&ctl->dbg_tile[2], 1u); atomicAdd(&ctl->dbg_tile[3], min(rn, RT_REGION_NC)); if (over) atomicAdd(&ctl->dbg_tile[4], 1u);
+        }
+        {
+            // a wave takes 4 of the region's blocks at once: 16 lanes per block, 16 records per step
+            const uint32_t sub = (uint32_t)lane >> 4, li = (uint32_t)lane & 15u, j = (uint32_t)wave * 4u + sub;
+            const uint32_t blk = G.block_of(reg, j);
+            const uint64_t trow = (uint64_t)(blk != 0xffffffffu ? blk : 0u) * nsl + ml;
+            float4 blo, bhi;             // (lane j of wave_union_box above held block j's box)
+            blo.x = __shfl(mylo.x, (int)j); blo.y = __shfl(mylo.y, (int)j); blo.z = __shfl(mylo.z, (int)j); blo.w = 0.0f;
+            bhi.x = __shfl(myhi.x, (int)j); bhi.y = __shfl(myhi.y, (int)j); bhi.z = __shfl(myhi.z, (int)j); bhi.w = 0.0f;
+            const UBeam Bb = ubeam_make(UL, F, blo, bhi, lp.sh_rays);
+            const bool go = blk != 0xffffffffu && Bb.ok && !over;
+            uint32_t c = 0u;
+            float4 *out = bb.trec + trow * (2u * RT_TILE_NC);
+            for (uint32_t i0 = 0; i0 < rn; i0 += 16u) {
+                if (!__any(go && c != RT_TILE_OVERFLOW)) break;
+                const uint32_t i = i0 + li;
+                bool keep = false;
+                float4 ra = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rb = ra;
+                if (go && c != RT_TILE_OVERFLOW && i < rn) {
+                    ra = recs[2u * i]; rb = recs[2u * i + 1u];
+                    LeafF lf;
+                    lf.x = ra.x; lf.y = ra.y; lf.z = ra.z; lf.r = ra.w; lf.lx = rb.x; lf.ly = rb.y; lf.lz = rb.z; lf.pk = __float_as_uint(rb.w);
+                    keep = ubeam_near(Bb, lf) && ubeam_touch(Bb, lf);
+                }
+                const uint32_t m16 = (uint32_t)(__ballot(keep) >> (sub * 16u)) & 0xffffu;
+                const uint32_t pos = c + (uint32_t)__popc(m16 & ((1u << li) - 1u)), tot = (uint32_t)__popc(m16);
+                if (c != RT_TILE_OVERFLOW) {
+                    if (c + tot > RT_TILE_NC) c = RT_TILE_OVERFLOW;
+                    else {
+                        if (keep) { out[2u * pos] = ra; out[2u * pos + 1u] = rb; }
+                        c += tot;
+                    }
+                }
+            }
+            if (blk != 0xffffffffu && li == 0u) {
+                const uint32_t cf = !Bb.ok ? 0u : (over ? RT_TILE_OVERFLOW : c);
+                bb.tcnt[trow] = cf;
+                if ((lp.flags & 0x1000) && Bb.ok) {
+                    atomicAdd(&ctl->dbg_tile[5], 1u);
+                    if (cf == RT_TILE_OVERFLOW) atomicAdd(&ctl->dbg_tile[7], 1u); else atomicAdd(&ctl->dbg_tile[6], cf);
+                }
+            }
+        }
+        if ((lp.flags & 0x2000) && threadIdx.x == 0) {
+            const long long tc3 = wall_clock64();
+            atomicAdd(&ctl->dbg_tcyc[0], (unsigned long long)(tc1 - tc0)); atomicAdd(&ctl->dbg_tcyc[1], (unsigned long long)(tc2 - tc1));
+            atomicAdd(&ctl->dbg_tcyc[2], (unsigned long long)(tc3 - tc2)); atomicMax(&ctl->dbg_tcyc[3], (unsigned long long)(tc3 - tc0));
+            atomicMax(&ctl->dbg_tile[0], zn);
+        }
+    }
+}
+
 // beam path: one lane per (hit, shadow light) pair (rt_shadow.hpp).  The basis is computed in float32 from the
 // float64 difference light - P; its error is part of the direction-error budget RT_RHO of the per-ray predicates.
 // A pair ends in one of three ways:
@@ -487,12 +855,16 @@ __device__ __forceinline__ void wave_append_flush(T *buf, uint32_t n, uint32_t *
 //   listed: header + candidate units go to rec[pair], the pair gets a slot in bb.list (wave-aggregated append);
 //   numerically delicate basis / too many candidates: listed with the overflow mark, all its rays go to the
 //     float64 queue.
-template <bool EARLY, bool BOXES>
+// TILES (level 0 of scenes with short beams): the pair filters the candidate row of its (block, light) (k_bin_block) instead of
+// walking the tree; the wave stays converged for that (rows are staged by all 64 lanes): lanes past the end of the hit list
+// repeat its last pair and store nothing.
+template <bool EARLY, bool BOXES, bool TILES>
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) k_beam_setup(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb, BeamBuf bb,
                                                          FrameCtl *ctl) {
     extern __shared__ uint2 lds_stack[];
     __shared__ uint32_t lbuf_all[(RT_BLOCK / 64) * 128], obuf_all[(RT_BLOCK / 64) * 128];
     __shared__ uint32_t tl_all[RT_TOUCH * RT_BLOCK];     // [entry][lane]: touched leaf entries of the lane's traversal
+    __shared__ float4 rowbuf_all[TILES ? (RT_BLOCK / 64) * 2 * RT_TILE_NC : 1];      // per wave: the candidate row being filtered
     if (ctl->overflow) return;
     if (lp.prio) __builtin_amdgcn_s_setprio(3);
     const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
@@ -520,9 +892,19 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
         const uint32_t seg = h * nsl + ml;
         bool listed = false, ovf = false;
         uint32_t list_nu = 0u;
-        if (valid) {
-            const uint32_t r = hb.list[h];
+        if (valid || TILES) {
+            const uint32_t r = hb.list[(valid || !TILES) ? h : n_hits - 1u];
             const int m = S.shadow_lights[ml];
+            // tile beams: the candidate row of the wave's first pair is requested now and used after the pair set-up below
+            // (most waves hold pairs of one block: one row)
+            TileRow T;
+            if (TILES) {
+                T.trec = bb.trec; T.tcnt = bb.tcnt; T.row = 0xffffffffu; T.lane = lane;
+                T.rowbuf = rowbuf_all + (threadIdx.x >> 6) * 2 * RT_TILE_NC;
+                T.pre_row = (uint32_t)__builtin_amdgcn_readfirstlane((int)((r >> 6) * nsl + ml));
+                T.pre = bb.trec[(uint64_t)T.pre_row * (2u * RT_TILE_NC) + (uint32_t)lane];
+                T.pre_cnt = bb.tcnt[T.pre_row];
+            }
             const d3 P = mk3(hb.px[r], hb.py[r], hb.pz[r]);
             const DLight &Lt = S.lights[m];
             const d3 dl = ld3(Lt.pos) - P;
@@ -588,25 +970,35 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                 }
             BeamOut bo;
             bo.nu = 0; bo.boxmask = 0; bo.overflow = true; bo.occ_all = false; bo.atp_all = false; bo.trips = 0; bo.why = 0;
-            if (!delicate) {
-                if (lp.flags & 0x100) bo.overflow = false;   // timing experiment only
+            if (!delicate || TILES) {
+                if (!TILES && (lp.flags & 0x100)) bo.overflow = false;   // timing experiment only
                 else {
                     LightQuad Q;
                     Q.u0 = u0; Q.u1 = u1; Q.u2 = u2; Q.r0 = r0; Q.r1 = r1; Q.r2 = r2;
                     const float ur = fabsf(u0 * r0) + fabsf(u1 * r1) + fabsf(u2 * r2);
                     Q.aq = (0.5f * sm1 * g + g * (1.0f + ur)) * 1.0001f + 1e-5f;
                     Q.ja = (g * ((fabsf(u0) + fabsf(r0)) * fabsf(D0) + (fabsf(u1) + fabsf(r1)) * fabsf(D1) + (fabsf(u2) + fabsf(r2)) * fabsf(D2))) * 1.0001f + 1e-5f;
+                    if (TILES) {
+                        // the pair's block has a candidate row when its sample box lies inside the base box the binning kernels
+                        // gave the block's union beam (always, up to rounding; a pair outside walks the tree itself)
+                        const float Rs = tile_light_half(radius, g);
+                        const float lim0 = Rs + RT_2M17 * (fabsf(cB0) + Rs) + 1e-5f, lim1 = Rs + RT_2M17 * (fabsf(cB1) + Rs) + 1e-5f, lim2 = Rs + RT_2M17 * (fabsf(cB2) + Rs) + 1e-5f;
+                        if (h0 <= lim0 && h1 <= lim1 && h2 <= lim2) T.row = (r >> 6) * nsl + ml;
+                        const bool active = valid && !delicate && !(lp.flags & 0x100);      // (0x100: timing experiment only)
+                        bo = beam_collect<RT_BLOCK, EARLY, BOXES, true>(S, F, bs, tl_all + threadIdx.x, P, cB0, cB1, cB2, h0, h1, h2, Q, rec + 4, lp.flags, active, &T);
+                        if (delicate) bo.overflow = true;
+                    } else
                     bo = beam_collect<RT_BLOCK, EARLY, BOXES>(S, F, bs, tl_all + threadIdx.x, P, cB0, cB1, cB2, h0, h1, h2, Q, rec + 4, lp.flags);
                 }
             }
 #ifdef RT_DEBUG_BEAM
-            if (lp.flags & 0x40000) {
+            if (valid && (lp.flags & 0x40000)) {
                 printf("[setup] pair %u light %d P %.17g %.17g %.17g delicate %d overflow %d why %u occ_all %d atp_all %d nu %u boxmask %x pcls %x trips %u cB %g %g %g h %g %g %g\n", seg, m, P.x, P.y, P.z,
                        (int)delicate, (int)bo.overflow, bo.why, (int)bo.occ_all, (int)bo.atp_all, bo.nu, bo.boxmask, pcls, bo.trips, cB0, cB1, cB2, h0, h1, h2);
                 for (uint32_t j = 0; j < RT_TOUCH; ++j) printf("[setup] touched[%u] = prim %u\n", j, tl_all[j * RT_BLOCK + threadIdx.x]);
             }
 #endif
-            if (lp.flags & 0x1000) {
+            if (valid && (lp.flags & 0x1000)) {
                 atomicMax(&ctl->dbg_max_trips, bo.trips); atomicAdd(&ctl->dbg_sum_trips, (unsigned long long)bo.trips);
                 if (bo.overflow) atomicAdd(&ctl->dbg_why[delicate ? 0 : bo.why], 1u);
             }
@@ -622,7 +1014,8 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
             // met the ground plane far out): nothing the beam found may be dropped - a pair that is "occluded as a whole" would
             // otherwise be listed WITHOUT the occluder.  Every ray of such a pair is decided in float64.
             if (!range_ok) { bo.overflow = true; delicate = true; }
-            if (whole) bb.pair_slot[(uint64_t)ml * lp.cap + h] = whole;
+            if (!valid) {}
+            else if (whole) bb.pair_slot[(uint64_t)ml * lp.cap + h] = whole;
             else if (bo.overflow) {
                 // too many primitives along the beam (or a delicate basis): k_shadow_walk sends each ray through the
                 // tree on its own; it needs the header only.  units = RT_META_OVERFLOW: float64 for every ray.
@@ -1578,6 +1971,7 @@ struct FrameState {
     uint64_t cap_deep = 0;  // ... of the levels >= 1: queues 1.., buffer sets 1.. (cap / deep_div)
     uint64_t fb_slots = 0;
     uint32_t beam_queue_cap = 0;
+    uint32_t tile_nblk = 0, tile_nreg = 0, tile_nzone = 0;      // what the binning buffers of the tile beams were carved for
     double qgrowth_carved = 1.0;    // float64 shadow-ray queue of a set = its capacity * this
     RayQ q[6]{};            // level 0 -> q[0]; level k >= 1 -> q[1 + (k - 1) % 2] (% 3 / % 5 when the deeper levels are pipelined over 2 / 4 sets)
     HitBuf hb{}, hb1{}, hb2{}, hb3{}, hb4{};   // level 0 / deeper levels, rotating (so are seg*, beam*)
@@ -1602,6 +1996,10 @@ struct EnvCfg {
     bool box_kernels = false;           // RT_AMD_BOX_KERNELS: box-capable kernel templates even without boxes
     bool no_prio = false, prio = false; // RT_AMD_NO_PRIO / RT_AMD_PRIO: wave priority of the deeper levels
     bool no_pipeline = false;           // RT_AMD_NO_PIPELINE: deeper levels on one stream
+    bool no_tiles = false;              // RT_AMD_NO_TILES: every pair walks the tree itself (no tile beams)
+    long long tiles_min = 1500000;      // RT_AMD_TILES_MIN: tile beams for frames of at least this many camera rays (the three small
+                                        // kernels in front of k_beam_setup cost more than they save on smaller frames)
+    int tiles_min_prims = 1024;         // RT_AMD_TILES_MIN_PRIMS: ... in scenes of at least this many primitives (tile_scene_ok)
     bool one_shadow_stream = false;     // RT_AMD_ONE_SHADOW_STREAM: soft shadows of all deeper levels on stream3 (diagnostic)
     bool debug = false;                 // RT_AMD_DEBUG: per-level diagnostics on stderr
     bool exact = false;                 // RT_AMD_EXACT: batched queries through the reference-order walk
@@ -1613,6 +2011,9 @@ struct EnvCfg {
         no_prio = getenv("RT_AMD_NO_PRIO") != nullptr; prio = getenv("RT_AMD_PRIO") != nullptr;
         no_pipeline = getenv("RT_AMD_NO_PIPELINE") != nullptr;
         one_shadow_stream = getenv("RT_AMD_ONE_SHADOW_STREAM") != nullptr;
+        no_tiles = getenv("RT_AMD_NO_TILES") != nullptr;
+        if (const char *v = getenv("RT_AMD_TILES_MIN")) tiles_min = atoll(v);
+        if (const char *v = getenv("RT_AMD_TILES_MIN_PRIMS")) tiles_min_prims = atoi(v);
         debug = getenv("RT_AMD_DEBUG") != nullptr;
         exact = getenv("RT_AMD_EXACT") != nullptr;
         if (const char *e = getenv("RT_AMD_OVL_MAIN")) ovl_main = atoi(e);
@@ -1624,6 +2025,7 @@ struct EnvCfg {
 struct rt_ctx : FrameState {
     int device = 0;
     EnvCfg env;
+    int64_t tile_frames = 0;                // frames enqueued with tile beams (rt_debug_tile_frames)
     unsigned char *stage = nullptr;         // grow-only device staging for the blocking host-buffer entry points (no hipMalloc per call)
     size_t stage_bytes = 0;
     uint32_t *d_voided = nullptr;           // frames voided by a queue overflow since the last rt_voided_frames(reset) (device counter)
@@ -1656,6 +2058,7 @@ struct rt_ctx : FrameState {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int nb_intersect = 1, nb_beam_setup = 1, nb_beam = 1, nb_queue = 1, nb_shade = 1, nb_setup = 1, nb_shadow = 1, nb_walk = 1;   // workgroups per CU
     int g_walk = 2048;
+    int g_beam_setup_t = 2048, nb_beam_setup_t = 1;
     FrameCtl *h_ctl = nullptr;   // pinned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> prof_ev;     // RT_FLAG_PROFILE: [gen0, gen1, (i0,i1,s0,s1,h0,h1) per level ..., res0, res1]
@@ -1722,6 +2125,7 @@ static int scratch_address(rt_ctx *ctx, int device, unsigned char **out) {
 }
 
 extern "C" int64_t rt_debug_alloc_calls(void) { return (int64_t)g_alloc_calls.load(); }
+extern "C" int64_t rt_debug_tile_frames(const rt_ctx *ctx) { return ctx ? ctx->tile_frames : 0; }
 extern "C" int64_t rt_noalloc_scratch_bytes(void) { return (int64_t)RT_SCRATCH_BYTES; }
 
 // host loops of rt_create over millions of independent records: cut into contiguous pieces, one thread each
@@ -2020,10 +2424,13 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow_queue, hipFuncAttributeMaxDynamicSharedMemorySize, big));
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow_walk, hipFuncAttributeMaxDynamicSharedMemorySize, big - 8192));   // 4 KB of static LDS (queue buffer)
             // 14 KB of static LDS (list buffer, touched entries)
-            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));
-            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));
-            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));
-            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));
+            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));
+            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));
+            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));
+            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));
+            // + 4 KB: the candidate rows of the tile beams
+            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 20480));
+            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 20480));
             HIP_C(hipFuncSetAttribute((const void *)&k_intersect_only<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
             HIP_C(hipFuncSetAttribute((const void *)&k_visibility<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         }
@@ -2050,7 +2457,8 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
         ctx->g_intersect_x = grid_for((const void *)&k_intersect<false, false>, 0);
         ctx->g_shadow = grid_for((const void *)&k_shadow<true>, lds); ctx->nb_shadow = last_nb;
         ctx->g_shadow_x = grid_for((const void *)&k_shadow<false>, 0);
-        ctx->g_beam_setup = grid_for((const void *)&k_beam_setup<false, true>, lds); ctx->nb_beam_setup = last_nb;
+        ctx->g_beam_setup = grid_for((const void *)&k_beam_setup<false, true, false>, lds); ctx->nb_beam_setup = last_nb;
+        ctx->g_beam_setup_t = grid_for((const void *)&k_beam_setup<false, true, true>, lds); ctx->nb_beam_setup_t = last_nb;
         ctx->g_beam = grid_for((const void *)&k_shadow_beam, 0); ctx->nb_beam = last_nb;
         ctx->g_queue = grid_for((const void *)&k_shadow_queue, lds); ctx->nb_queue = last_nb;
         ctx->g_walk = grid_for((const void *)&k_shadow_walk, lds); ctx->nb_walk = last_nb;
@@ -2211,9 +2619,14 @@ struct Carver {
     }
 };
 
+// Tile beams pay in scenes whose tree takes a pair tens of node steps to walk and whose beams meet few primitives: measured
+// -6 % (1920x1080) to -16 % (3840x2160) on the 10 k lattice, +5 % on the 20-primitive pool scene (nothing to save there), no
+// change at 90 k primitives (half of the rows overflow).  A rule of the scene, like every other choice of kernels here.
+static bool tile_scene_ok(const rt_ctx *ctx) { return ctx->F.ok && ctx->S.n_prims >= ctx->env.tiles_min_prims && ctx->S.n_prims <= (int)RT_ZONE_NC; }
+
 // Carve the state of a frame of `slots` primary slots with queue capacity `cap` into fs.  sets = 1..3 buffer sets (level 0 /
 // deeper levels odd / even); queues = 3 (levels in sequence) or 4 (pipelined deeper levels).  Nothing is initialised here.
-static int carve_frame(rt_ctx *ctx, Carver &mem, FrameState &fs, uint64_t slots, uint64_t cap0, uint64_t cap_deep, double qgrowth, int sets, int queues) {
+static int carve_frame(rt_ctx *ctx, Carver &mem, FrameState &fs, uint64_t slots, uint64_t cap0, uint64_t cap_deep, double qgrowth, int sets, int queues, bool tiles) {
 #define TRY_A(expr) do { int rc_ = (expr); if (rc_ != RT_OK) return rc_; } while (0)
     if (sets < 2) cap_deep = cap0;          // one set: every level lives in it
     auto qcap = [&](uint64_t c) { const double v = (double)c * qgrowth; return (uint32_t)(v < 2147483647.0 ? v : 2147483647.0); };
@@ -2244,6 +2657,18 @@ static int carve_frame(rt_ctx *ctx, Carver &mem, FrameState &fs, uint64_t slots,
         TRY_A(mem.get(&bb.queue, (uint64_t)queue_cap)); TRY_A(mem.get(&bb.queue_n, 4));
         TRY_A(mem.get(&bb.litbits, (nlit + 1) * (RT_BLOCK / 64)));      // worst case one pair per chunk (s*s > RT_BLOCK / 2)
         TRY_A(mem.get(&bb.list, nlit)); TRY_A(mem.get(&bb.pair_slot, nlit)); TRY_A(mem.get(&bb.ovlist, nlit));
+        bb.blockbox = nullptr; bb.trec = nullptr; bb.tcnt = nullptr; bb.zlist = bb.zcnt = nullptr;
+        if (set == 0) { fs.tile_nblk = fs.tile_nreg = fs.tile_nzone = 0; }
+        if (set == 0 && tiles && tile_scene_ok(ctx)) {
+            // tile beams serve level 0, which always runs on the first set.  Regions / zones: twice what a frame of square-ish
+            // tiles needs (ragged edges of the block grid); a frame that needs more runs without tile beams
+            const uint64_t nblk = (slots + 63) / 64, nreg = nblk / 8 + 64, nzone = nreg / 16 + 8;
+            const uint64_t zcap = std::min<uint64_t>((uint64_t)ctx->S.n_prims, RT_ZONE_NC);
+            TRY_A(mem.get(&bb.blockbox, nblk * 8));
+            TRY_A(mem.get(&bb.trec, nblk * nsl1 * 2 * RT_TILE_NC)); TRY_A(mem.get(&bb.tcnt, nblk * nsl1));
+            TRY_A(mem.get(&bb.zlist, nzone * nsl1 * zcap)); TRY_A(mem.get(&bb.zcnt, nzone * nsl1));
+            fs.tile_nblk = (uint32_t)nblk; fs.tile_nreg = (uint32_t)nreg; fs.tile_nzone = (uint32_t)nzone;
+        }
     }
     if (sets < 2) { fs.hb1 = fs.hb; fs.seg1 = fs.seg; fs.beam1 = fs.beam; }
     if (sets < 3) { fs.hb2 = fs.hb1; fs.seg2 = fs.seg1; fs.beam2 = fs.beam1; }
@@ -2324,7 +2749,7 @@ static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
     Carver mem{ctx};
     FrameState fs;
     fs.ctl = ctx->ctl_own;
-    int rc = carve_frame(ctx, mem, fs, slots, cap, want_deep, ctx->qgrowth, sets, sets >= 5 ? 6 : 4);
+    int rc = carve_frame(ctx, mem, fs, slots, cap, want_deep, ctx->qgrowth, sets, sets >= 5 ? 6 : 4, !ctx->env.no_tiles);
     if (rc == RT_OK) rc = init_frame_counters(ctx, fs, ctx->stream);
     if (rc == RT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, RT_ERR_HIP, "hipStreamSynchronize failed after frame set-up");
     if (rc != RT_OK) { free_frame(ctx); return rc; }
@@ -2434,13 +2859,15 @@ static int prof_bs_prepare(rt_ctx *ctx, int levels) {
 // hits(L) reuses the buffer set and ray queue of level L-2 and waits for that level's shading.
 // fbm: where the rays of levels 1.. add the background when they miss (may be fb itself when nothing overlaps).
 static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, int32_t rec, int32_t *d_ids, hipStream_t st,
-                          double *fb0, const GenParams *gen, double *fbm) {
+                          double *fb0, const GenParams *gen, double *fbm, const GenParams *cam) {
     LevelParams lp{};
+    bool tiles = false;
     lp.sh_rays = sh; lp.jitter = p->jitter; lp.seed = p->seed; lp.cap = (uint32_t)ctx->cap; lp.cap_next = (uint32_t)ctx->cap_deep; lp.flags = p->flags;
     auto set_level = [&](int level) {
         lp.level = level;
         lp.last_level = (level == rec) ? 1 : 0;
         lp.cap = (uint32_t)(level == 0 ? ctx->cap : ctx->cap_deep);
+        lp.tiles = (tiles && level == 0) ? 1 : 0;
     };
     lp.unit_thr = gen ? 1 : 0;
     {
@@ -2460,6 +2887,14 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
     const bool beam = fast && ctx->S.n_planes <= RT_PMAX && !(p->flags & RT_FLAG_NO_BEAM) && s2 >= 9 && s2 <= RT_BLOCK &&
                       ctx->S.n_lights <= 256 &&   // pair record: 8-bit light index
                       ctx->cap * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1) < (1ull << RT_LIST_NU_SHIFT);   // list entry: pair | units << 28
+    // tile beams (level 0 of a camera frame in 8 x 8 tiles: the rays of a block of 64 slots are the pixels of a tile, their beams
+    // towards a light nearly one beam); the binning buffers were carved for the frame sizes this context has seen
+    if (beam && cam && cam->tw * cam->th == 64 && (long long)cam->n_slots >= ctx->env.tiles_min && !lp.beam_early && !ctx->env.no_tiles && !(p->flags & RT_FLAG_NO_TILES) && ctx->beam.trec != nullptr) {
+        lp.tile_stride = (uint32_t)std::max(1, (cam->tiles_x + cam->world / 2) / std::max(cam->world, 1));
+        const TileGrid G(cam->n_slots, lp.tile_stride);
+        tiles = G.nblk <= ctx->tile_nblk && G.nreg <= ctx->tile_nreg && G.nzone <= ctx->tile_nzone;
+        if (tiles) ++ctx->tile_frames;
+    }
     if (s2 > 0 && s2 <= RT_BLOCK) {
         lp.spb = RT_BLOCK / s2;
         lp.beam = beam ? 1 : 0;
@@ -2493,10 +2928,20 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                 const dim3 gs(gsz(ctx->g_beam_setup, ctx->nb_beam_setup, side));
                 const bool boxes = ctx->n_boxes > 0 || ctx->env.box_kernels;
                 if (time_bs) HIP_TRY(ctx, hipEventRecord(ctx->prof_bs[2 * level], s_));      // the frame's dominant kernel on its own (bench.py: roofline)
-                if (lp.beam_early && boxes) hipLaunchKernelGGL((k_beam_setup<true, true>), gs, block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
-                else if (lp.beam_early) hipLaunchKernelGGL((k_beam_setup<true, false>), gs, block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
-                else if (boxes) hipLaunchKernelGGL((k_beam_setup<false, true>), gs, block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
-                else hipLaunchKernelGGL((k_beam_setup<false, false>), gs, block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
+                if (lp.tiles) {
+                    // candidates per (block, light) by binning; small flat kernels in front of the pairs' own pass
+                    const dim3 gt((ctx->n_cu * 8 + 7) & ~7);       // (small kernels of few registers: they fit beside whatever else is resident)
+                    hipLaunchKernelGGL(k_block_box, gt, block, 0, s_, ctx->S, lp, hb, bb, ctx->ctl);
+                    hipLaunchKernelGGL(k_bin_zone, gt, block, 0, s_, ctx->S, ctx->F, lp, bb, ctx->ctl);
+                    hipLaunchKernelGGL(k_bin_tiles, gt, block, 0, s_, ctx->S, ctx->F, lp, bb, ctx->ctl);
+                    const dim3 gst(gsz(ctx->g_beam_setup_t, ctx->nb_beam_setup_t, side));
+                    if (boxes) hipLaunchKernelGGL((k_beam_setup<false, true, true>), gst, block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
+                    else hipLaunchKernelGGL((k_beam_setup<false, false, true>), gst, block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
+                }
+                else if (lp.beam_early && boxes) hipLaunchKernelGGL((k_beam_setup<true, true, false>), gs, block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
+                else if (lp.beam_early) hipLaunchKernelGGL((k_beam_setup<true, false, false>), gs, block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
+                else if (boxes) hipLaunchKernelGGL((k_beam_setup<false, true, false>), gs, block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
+                else hipLaunchKernelGGL((k_beam_setup<false, false, false>), gs, block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
                 if (time_bs) { HIP_TRY(ctx, hipEventRecord(ctx->prof_bs[2 * level + 1], s_)); ctx->prof_bs_levels = level + 1; }
             }
             hipLaunchKernelGGL(k_shadow_beam, dim3(gsz(ctx->g_beam, ctx->nb_beam, side == 1 ? 3 : side)), block, 0, s_, ctx->S, lp, hb, bb, ctx->ctl);
@@ -2700,7 +3145,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_render_params *p, const TileGeom 
         PROF_MARK(0);
         if (prof) hipLaunchKernelGGL(k_gen, grid, block, 0, st, gp, ctx->q[0], ctx->ctl);
         PROF_MARK(1);
-        if (int rc = enqueue_levels(ctx, p, sh, rec, d_ids, st, ctx->fb0, prof ? nullptr : &gp, ctx->fbm)) return rc;
+        if (int rc = enqueue_levels(ctx, p, sh, rec, d_ids, st, ctx->fb0, prof ? nullptr : &gp, ctx->fbm, &gp)) return rc;
     }
     PROF_MARK(2 + 6 * (rec + 1));
     if (d_rgb || d_rgb8) hipLaunchKernelGGL(k_resolve, grid, block, 0, st, ctx->fb, ctx->fb0, ctx->fbm, g.out_slots * 3, d_rgb, d_rgb8, ctx->ctl, ctx->d_voided);
@@ -2762,7 +3207,7 @@ extern "C" int rt_render_device_noalloc(rt_ctx *ctx, const rt_render_params *p, 
     mem.limit = RT_SCRATCH_BYTES;
     FrameState fs;
     if (int rc = mem.get(&fs.ctl, 1)) return rc;
-    if (int rc = carve_frame(ctx, mem, fs, slots, cap, cap, 1.0, 1, 3)) {
+    if (int rc = carve_frame(ctx, mem, fs, slots, cap, cap, 1.0, 1, 3, false)) {
         char msg[256];
         snprintf(msg, sizeof(msg), "rt_render_device_noalloc: a frame of %llu pixel slots with %d shadow-casting lights does not fit the %llu MiB static scratch buffer",
                  (unsigned long long)slots, ctx->S.n_shadow_lights, (unsigned long long)(RT_SCRATCH_BYTES >> 20));
@@ -2830,6 +3275,12 @@ extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
                     (unsigned long long)c.n_hits[l] * (unsigned long long)ctx->S.n_shadow_lights, c.n_listed[l], c.n_walked[l], c.n_queued[l]);
         fprintf(stderr, "[rt_amd] beam traversal trips (flag 0x1000): max %u, total %llu; pairs to the queue: delicate %u, touched %u, units %u, dedup %u\n",
                 c.dbg_max_trips, c.dbg_sum_trips, c.dbg_why[0], c.dbg_why[1], c.dbg_why[2], c.dbg_why[3]);
+        if (c.dbg_tile[2])
+            fprintf(stderr, "[rt_amd] tile beams (flag 0x1000): %u (region, light) rows scanned %u zone-list entries and kept %u (%u overflowing); %u (block, light) rows list %u candidates (%u overflowing)\n",
+                    c.dbg_tile[2], c.dbg_tile[1], c.dbg_tile[3], c.dbg_tile[4], c.dbg_tile[5], c.dbg_tile[6], c.dbg_tile[7]);
+        if (c.dbg_tcyc[3])
+            fprintf(stderr, "[rt_amd] tile beams: longest zone list %u; clocks of thread 0 over all rows: set-up %llu, region filter %llu, block filter %llu; longest row %llu\n",
+                    c.dbg_tile[0], c.dbg_tcyc[0], c.dbg_tcyc[1], c.dbg_tcyc[2], c.dbg_tcyc[3]);
         // candidate units of the listed pairs of the LAST level (render with rec_max = 0 to see level 0)
         uint32_t qn[4] = {0, 0, 0, 0};
         (void)hipMemcpy(qn, ctx->beam.queue_n, sizeof(qn), hipMemcpyDeviceToHost);
@@ -3018,7 +3469,7 @@ extern "C" int rt_trace(rt_ctx *ctx, const rt_render_params *p, const double *or
             pp.flags &= ~(RT_FLAG_PROFILE | RT_FLAG_TIME_DOMINANT);
             ctx->prof_bs_levels = 0;
             ctx->prof_levels = -1;
-            rc = enqueue_levels(ctx, &pp, sh, rec, nullptr, st, ctx->fb, nullptr, ctx->fb);   // one framebuffer: rgb_out is its raw float64 content
+            rc = enqueue_levels(ctx, &pp, sh, rec, nullptr, st, ctx->fb, nullptr, ctx->fb, nullptr);   // one framebuffer: rgb_out is its raw float64 content
             if (rc != RT_OK) break;
         }
         hipLaunchKernelGGL(k_frame_end, dim3(1), dim3(64), 0, st, ctx->ctl, ctx->d_voided);

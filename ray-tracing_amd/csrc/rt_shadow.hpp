@@ -50,7 +50,18 @@ struct BeamBuf {
     uint32_t *list;          // [slot] -> pair: the pairs whose rays need the per-ray filter, in no particular order
     uint32_t *pair_slot;     // [pair] -> slot, or RT_PAIR_LIT / RT_PAIR_UNLIT when the whole pair is decided
     unsigned long long *litbits; // [chunk of slots][wave]: which lanes' rays the filter found lit (every word written per level)
+    // tile beams (level 0 of scenes with short beams; set 0 only): candidates per (block of 64 ray slots, shadow light), found by
+    // binning the primitives against the union of the block's beams, zone -> region -> block (k_bin_*, rt_amd.hip)
+    float *blockbox;         // [block][8]: min xyz, max xyz of the block's hit points, rounded outward (min > max: no hit)
+    float4 *trec;            // [block * n_shadow_lights + light][2 * RT_TILE_NC]: the row's candidates, as their 32-byte leaf records
+    uint32_t *tcnt;          // [block * n_shadow_lights + light]: candidates in the row, or RT_TILE_OVERFLOW
+    uint32_t *zlist, *zcnt;  // [zone * n_shadow_lights + light][min(n_prims, RT_ZONE_NC)]: canonical leaf entries of the primitives near the zone's union beam / their number
 };
+#define RT_TILE_NC 32u                  // candidates a (block, light) row holds: 1 KB, one float4 per lane of a wave
+#define RT_REGION_NC 512u               // ... a (region, light) keeps in LDS
+#define RT_ZONE_NC 32768u               // ... a (zone, light) row (or every primitive of a smaller scene)
+#define RT_REGION_BLOCKS 16u            // a region = 4 x 4 blocks (32 x 32 pixels), a zone = 64 regions
+#define RT_TILE_OVERFLOW 0xFFFFFFFFu    // more candidates than the row holds: the pairs concerned walk the tree themselves
 #define RT_PAIR_LIT 0xFFFFFFFFu
 #define RT_PAIR_UNLIT 0xFFFFFFFEu
 #define RT_META_OVERFLOW 0xFu
@@ -239,9 +250,23 @@ struct BeamOut {
 // The margins (1e-3 relative on the angles, bm = 1e-3 r) dwarf float32 and float64 rounding.
 // EARLY (scenes with long beams): near side first, umbra test inside the traversal (see the loop).
 // BOXES = false (scenes without boxes): every leaf entry is a sphere, the box arithmetic folds away.
-template <int STRIDE, bool EARLY, bool BOXES>
+// TILES (k_beam_setup<.., true>, level 0): called by all 64 lanes of a wave together (on = false: the lane has no pair, or a
+// delicate one, and only helps staging); the lane's (block, light) row - trec / tcnt / row, row == 0xffffffff: none - lists the
+// primitives that the union of the block's beams can touch, and the lane keeps those its own beam can touch instead of walking
+// the tree.  rowbuf: the wave's LDS slice for one row (2 * RT_TILE_NC float4); pre_row / pre / pre_cnt: a row already in registers.
+struct TileRow {
+    const float4 *__restrict__ trec;
+    const uint32_t *__restrict__ tcnt;
+    uint32_t row;
+    float4 *rowbuf;
+    int lane;
+    uint32_t pre_row, pre_cnt;
+    float4 pre;
+};
+template <int STRIDE, bool EARLY, bool BOXES, bool TILES = false>
 __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene &F, uint2 *stk, uint32_t *tl, d3 P, float cB0, float cB1,
-                                                float cB2, float h0, float h1, float h2, const LightQuad &Q, float4 *out, int dbg) {
+                                                float cB2, float h0, float h1, float h2, const LightQuad &Q, float4 *out, int dbg,
+                                                bool on = true, const TileRow *T = nullptr) {
     BeamOut R;
     R.nu = 0; R.boxmask = 0; R.overflow = false; R.occ_all = false; R.atp_all = false; R.trips = 0; R.why = 0;
     const float Pf0 = (float)P.x, Pf1 = (float)P.y, Pf2 = (float)P.z;
@@ -267,16 +292,85 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
     clip_mul(l0, l1, -U0, -iU0, -((F.root_lo[0] - Pf0) - E)); clip_mul(l0, l1, L0, iL0, (F.root_hi[0] - Pf0) + E);
     clip_mul(l0, l1, -U1, -iU1, -((F.root_lo[1] - Pf1) - E)); clip_mul(l0, l1, L1, iL1, (F.root_hi[1] - Pf1) + E);
     clip_mul(l0, l1, -U2, -iU2, -((F.root_lo[2] - Pf2) - E)); clip_mul(l0, l1, L2, iL2, (F.root_hi[2] - Pf2) + E);
-    if (!(l0 <= l1)) return R;
     // The light's sample box is wider than it is far (a light of radius 10 inside a scene of extent 4: original.txt): the beam is
     // no beam, it meets everything near P - its rays are decided one by one, the walk below would only end in an overflow.
-    if (rho2 > 1.0f) { R.overflow = true; R.why = 1; return R; }
+    const bool wide = rho2 > 1.0f;
+    const bool live = on && l0 <= l1;                // else: no pair here, or its beam misses the root box
+    if (!TILES) {
+        if (!live) return R;
+        if (wide) { R.overflow = true; R.why = 1; return R; }
+    }
+    const uint32_t NONE = 0xffffffffu;
+    uint32_t nt = 0, ntu = 0;                        // touched entries, and the candidate units they would need
+    bool use_walk = true;
+    if (TILES) {
+        // ---- phase 1, tile beams.  Lanes of a wave share one or two rows: a row is staged into the wave's LDS slice by all 64
+        // lanes (one float4 each), distinct rows take turns.  The lane tests the row's primitives against its own beam with the
+        // box and cone tests of the walk's leaf loop - no tree, no duplicates.  An overflowing row sends its lanes through the tree.
+        use_walk = live && !wide && T->row == NONE;
+        const float m0 = fmaxf(l0 - 1e-6f, 0.0f), m1 = fminf(l1 + 1e-6f, 1.0f);
+        const float blo0 = fminf(m0 * L0, m1 * L0) - E, bhi0 = fmaxf(m0 * U0, m1 * U0) + E;
+        const float blo1 = fminf(m0 * L1, m1 * L1) - E, bhi1 = fmaxf(m0 * U1, m1 * U1) + E;
+        const float blo2 = fminf(m0 * L2, m1 * L2) - E, bhi2 = fmaxf(m0 * U2, m1 * U2) + E;
+        bool pending = live && !wide && T->row != NONE;
+        for (;;) {
+            const unsigned long long pm = __ballot(pending);
+            if (!pm) break;
+            const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)T->row, __ffsll((long long)pm) - 1);
+            const bool mine = pending && T->row == cur;
+            float4 part = T->pre;                        // the row requested ahead (k_beam_setup), or
+            uint32_t cnt = T->pre_cnt;
+            if (cur != T->pre_row) {
+                part = T->trec[(uint64_t)cur * (2u * RT_TILE_NC) + (uint32_t)T->lane];      // (entries past the count: never read)
+                cnt = T->tcnt[cur];
+            }
+            cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
+            if (dbg & 0x10000) cnt = 0u;                 // timing experiment only
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // earlier reads of the slice are done (WAR)
+            __builtin_amdgcn_wave_barrier();
+            T->rowbuf[T->lane] = part;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (cnt == RT_TILE_OVERFLOW) {
+                if (mine) use_walk = true;
+            } else {
+                for (uint32_t j = 0; j < cnt; ++j) {
+                    const float4 ra = T->rowbuf[2u * j], rb4 = T->rowbuf[2u * j + 1u];
+                    const uint32_t pk = __float_as_uint(rb4.w);
+                    const bool sph = !BOXES || (pk & 3u) == 1u;     // sphere {centre, r, (low parts)}; box {lo, -, hi}
+                    const float rr = sph ? ra.w : 0.0f;
+                    const float c0 = ra.x - Pf0, c1 = ra.y - Pf1, c2 = ra.z - Pf2;
+                    const float d0 = sph ? c0 : rb4.x - Pf0, d1 = sph ? c1 : rb4.y - Pf1, d2 = sph ? c2 : rb4.z - Pf2;
+                    bool keep = mine && !(c0 - rr > bhi0) && !(d0 + rr < blo0) && !(c1 - rr > bhi1) && !(d1 + rr < blo1) &&
+                                !(c2 - rr > bhi2) && !(d2 + rr < blo2);
+                    if (cone_ok) {                           // as in the walk's leaf loop
+                        const float m0_ = sph ? c0 : 0.5f * (c0 + d0), m1_ = sph ? c1 : 0.5f * (c1 + d1), m2_ = sph ? c2 : 0.5f * (c2 + d2);
+                        const float e0_ = d0 - c0, e1_ = d1 - c1, e2_ = d2 - c2;
+                        const float rb = sph ? ra.w : 0.5f * __builtin_amdgcn_sqrtf(fmaf(e0_, e0_, fmaf(e1_, e1_, e2_ * e2_))) * 1.000001f;
+                        const float ta = fmaf(m0_, ax0, fmaf(m1_, ax1, m2_ * ax2));
+                        const float k0 = fmaf(m1_, ax2, -(m2_ * ax1)), k1 = fmaf(m2_, ax0, -(m0_ * ax2)), k2 = fmaf(m0_, ax1, -(m1_ * ax0));
+                        const float dp2 = fmaf(k0, k0, fmaf(k1, k1, k2 * k2));
+                        const float cn = (fabsf(m0_) + fabsf(m1_)) + fabsf(m2_);      // >= |centre|
+                        const float lim = fmaf(rb, 1.0f + kt, fmaxf(ta, 0.0f) * kt) + E + 2e-6f * cn;
+                        keep = keep && !(dp2 > lim * lim * 1.0001f) && !(ta < -(rb + E)) && !(ta > ax_len * (1.0f + kt) + rb + E);
+                    }
+                    if (keep) {
+                        if (nt < RT_TOUCH) tl[nt * STRIDE] = pk >> 2;
+                        ++nt;
+                        ntu += sph ? 1u : 2u;
+                    }
+                }
+            }
+            if (mine) pending = false;
+        }
+    }
 
     // ---- phase 1: traversal.  The loops carry only the traversal state; a leaf entry that passes the float32
     // tests is parked (its primitive number, once) in the lane's LDS list tl[] (RT_TOUCH entries) and looked at
     // after the traversal.
-    const uint32_t NONE = 0xffffffffu;
-    uint32_t node = 0, nt = 0, ntu = 0;              // touched entries, and the candidate units they would need
+    if (use_walk) {
+    uint32_t node = 0;
     int sp = 0;
     for (;;) {
         // descend to a leaf (left first; the right child waits on the stack when the beam reaches both)
@@ -391,6 +485,11 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
         const uint2 t = stk[sp * STRIDE];
         node = t.x;
         unpack_lambda(t.y, l0, l1);
+    }
+    }
+    if (TILES) {
+        if (!live) return R;
+        if (wide) { R.overflow = true; R.why = 1; return R; }
     }
     if (nt > RT_TOUCH || ntu > RT_CUNITS + 4u || (dbg & 0x2000)) { R.overflow = true; R.why = 1; return R; }
 

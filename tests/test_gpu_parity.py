@@ -350,6 +350,30 @@ def _stress_ctx(kind):
     return _STRESS[kind][1]
 
 
+class _ctx_with_env:
+    """A fresh context created under the given RT_AMD_* switches (the library reads them once, in rt_create)."""
+
+    def __init__(self, packed, env):
+        self.packed, self.env = packed, env
+
+    def __enter__(self):
+        old = {k: os.environ.get(k) for k in self.env}
+        os.environ.update(self.env)
+        try:
+            self.ctx = native.Context(self.packed, device=0)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        return self.ctx
+
+    def __exit__(self, *exc):
+        self.ctx.close()
+        return False
+
+
 @pytest.mark.parametrize("kind,sh,jitter", [("wide", 5, True), ("wide", 3, False), ("hard", 5, True), ("hard", 16, True),
                                             ("inside", 4, True), ("inside", 7, False), ("boxes", 5, True),
                                             ("boxes", 3, True), ("plain", 9, True)])
@@ -422,24 +446,55 @@ def test_rays_of_overflowing_pairs_walk_or_expand_to_the_same_frame(gpu_ctx, kin
     the float32 filtered predicates (k_shadow_walk, RT_AMD_WALK_MIN=1 forces it) or are expanded into the float64
     kernel (RT_AMD_WALK_MIN=-1).  Same frame bit for bit, and the same as the reference-order walk."""
     ctx = gpu_ctx(kind) if kind in ("original", "synth400") else _stress_ctx(kind)       # original.txt: every pair overflows
+    packed = load_scene(kind)["packed"] if kind in ("original", "synth400") else _STRESS[kind][0].packed
     prm = abi.render_params(160, 100, sh_rays=sh, rec_max=3, jitter=jitter, seed=9)
     exact = ctx.render(abi.render_params(160, 100, sh_rays=sh, rec_max=3, jitter=jitter, seed=9, flags=abi.RT_FLAG_EXACT_TRAVERSAL))
-    old = {k: os.environ.get(k) for k in ("RT_AMD_WALK_MIN", "RT_AMD_BEAM_EARLY")}
     outs = {}
-    try:
-        for v, early in (("1", "0"), ("-1", "0"), ("1", "1"), ("-1", "1")):      # early: umbra test inside the beam traversal
-            os.environ["RT_AMD_WALK_MIN"] = v
-            os.environ["RT_AMD_BEAM_EARLY"] = early
-            outs[v + early] = ctx.render(prm)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    for v, early in (("1", "0"), ("-1", "0"), ("1", "1"), ("-1", "1")):      # early: umbra test inside the beam traversal
+        with _ctx_with_env(packed, {"RT_AMD_WALK_MIN": v, "RT_AMD_BEAM_EARLY": early}) as c2:      # (read once, in rt_create)
+            outs[v + early] = c2.render(prm)
     for out in outs.values():
         assert np.array_equal(out["ids"], exact["ids"]) and np.array_equal(out["rgb"], exact["rgb"])
         assert out["stats"]["rays"] == exact["stats"]["rays"]
+
+
+TILE_ENV = {"RT_AMD_TILES_MIN": "1", "RT_AMD_TILES_MIN_PRIMS": "1"}      # tile beams on frames / scenes of any size
+
+
+@pytest.mark.parametrize("kind,sh,jitter", [("synth400", 5, True), ("synth400", 3, False), ("small", 4, True), ("pool", 3, True),
+                                            ("original", 3, True), ("hard", 5, True), ("boxes", 5, True), ("boxes", 3, False),
+                                            ("inside", 4, True), ("wide", 5, True), ("plain", 6, True)])
+def test_tile_beams_give_the_same_frames(gpu_ctx, kind, sh, jitter):
+    """Level 0 of large frames: the candidates of a (hit, light) pair come from the row that the binning kernels made for its
+    8 x 8 pixel tile (k_block_box, k_bin_zone, k_bin_tiles) instead of the pair's own walk through the tree.  Same frame bit
+    for bit as with RT_FLAG_NO_TILES and as the reference-order walk: whole frames with ragged edges, tile partitions,
+    frames in a row of different sizes on one context."""
+    named = kind in ("synth400", "small", "pool", "original")
+    if not named:
+        _stress_ctx(kind)
+    packed = load_scene(kind)["packed"] if named else _STRESS[kind][0].packed
+    with _ctx_with_env(packed, TILE_ENV) as ctx:
+        used = 0
+        for (w, h, rank, world) in ((200, 120, 0, 1), (67, 45, 0, 1), (256, 144, 1, 3), (8, 8, 0, 1), (131, 77, 1, 2)):
+            kw = dict(sh_rays=sh, rec_max=2, jitter=jitter, seed=5, rank=rank, world=world)
+            before = native.lib().rt_debug_tile_frames(ctx._h)
+            tiles = ctx.render(abi.render_params(w, h, **kw))
+            used += native.lib().rt_debug_tile_frames(ctx._h) - before
+            plain = ctx.render(abi.render_params(w, h, flags=abi.RT_FLAG_NO_TILES, **kw))
+            exact = ctx.render(abi.render_params(w, h, flags=abi.RT_FLAG_EXACT_TRAVERSAL, **kw))
+            for other in (plain, exact):
+                assert np.array_equal(tiles["ids"], other["ids"])
+                assert np.array_equal(tiles["rgb"], other["rgb"])
+                assert tiles["stats"]["rays"] == other["stats"]["rays"]
+        assert used == 5, "the frames did not take the tile beams"
+
+
+def test_tile_beams_are_a_rule_of_scene_and_frame_size(gpu_ctx):
+    """Default thresholds: frames below 1.5 M camera rays and scenes below 1024 primitives keep the pairs' own walks."""
+    ctx = gpu_ctx("synth400")
+    before = native.lib().rt_debug_tile_frames(ctx._h)
+    ctx.render(abi.render_params(320, 180, sh_rays=3, rec_max=1, jitter=True, seed=1))
+    assert native.lib().rt_debug_tile_frames(ctx._h) == before
 
 
 def _glass_scene(tmp_path):

@@ -123,11 +123,11 @@ def test_flag_constants_match_the_header():
     with open(os.path.join(ROOT, "include", "rt_amd.h")) as f:
         header = f.read()
     flags = dict(re.findall(r"^#define (RT_FLAG_[A-Z_]+) (\d+)", header, flags=re.M))
-    assert set(flags) == {"RT_FLAG_EXACT_TRAVERSAL", "RT_FLAG_PROFILE", "RT_FLAG_NO_BEAM", "RT_FLAG_NO_OVERLAP", "RT_FLAG_NO_SMALL", "RT_FLAG_TIME_DOMINANT"}
+    assert set(flags) == {"RT_FLAG_EXACT_TRAVERSAL", "RT_FLAG_PROFILE", "RT_FLAG_NO_BEAM", "RT_FLAG_NO_OVERLAP", "RT_FLAG_NO_SMALL", "RT_FLAG_TIME_DOMINANT", "RT_FLAG_NO_TILES"}
     for name, value in flags.items():
         assert getattr(abi, name) == int(value), name
     values = sorted(int(v) for v in flags.values())
-    assert values == [1, 2, 4, 8, 16, 32]
+    assert values == [1, 2, 4, 8, 16, 32, 64]
 
 
 def test_no_gpu_is_an_error_not_a_fallback():
