@@ -337,16 +337,22 @@ def main():
         ms_kernel = prof["ms_beam_setup"]
         launches = prof["beam_setup_launches"] or live_launches
         pmc, pmc_path, pmc_hits = profile_file(args.workload, W, H, world)
-        kname = next((k for k in (pmc["kernels"] if pmc else {}) if k.startswith("k_beam_setup")), None)
+        # the kernel is a template: level 0 of a large frame runs the instance that filters the candidate rows of the tile beams,
+        # the other levels the one that walks the tree - the events bracket the launches of both, the counters are added up
+        knames = sorted((k for k in (pmc["kernels"] if pmc else {}) if k.startswith("k_beam_setup")),
+                        key=lambda k: -pmc["kernels"][k]["executed_flop_per_frame"])
+        kname = knames[0] if knames else None
         same_shape = (W, H, world) == (1920, 1080, 1) and args.sh_rays is None and args.rec_max is None
         pair_scale = 1.0 if same_shape else (prof["hits"] / float(pmc_hits) if pmc_hits else None)
-        executed = pmc["kernels"][kname]["executed_flop_per_frame"] * pair_scale if (kname and pair_scale) else None
+        executed = sum(pmc["kernels"][k]["executed_flop_per_frame"] for k in knames) * pair_scale if (kname and pair_scale) else None
+        hbm = sum(pmc["kernels"][k].get("hbm_bytes_per_frame") or 0 for k in knames)
         achieved = executed / (ms_kernel * 1e-3) / 1e12 if (executed and ms_kernel > 0) else None
         roofline = {
             "bound": "valu", "kernel": kname or "k_beam_setup",
             "achieved": round(achieved, 3) if achieved is not None else None, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4) if achieved is not None else None,
-            "traffic": (pmc["kernels"][kname].get("hbm_bytes_per_frame") or 0) * pair_scale if (kname and pair_scale) else None,
+            "traffic": hbm * pair_scale if (kname and pair_scale) else None,
+            "kernel_instances": knames,
             "executed_work_scaled_by_pairs": None if same_shape else pair_scale,
             "traffic_unit": "HBM-side bytes of the kernel's launches of one frame (2 x FETCH_SIZE + WRITE_SIZE)",
             "achieved_is": "floating-point operations the kernel EXECUTES per frame (hardware counters: ADD + MUL + TRANS + 2 FMA, "

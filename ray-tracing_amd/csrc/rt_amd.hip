@@ -2927,13 +2927,15 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                 // the kernel template that fits the scene: long beams or not, boxes or spheres only
                 const dim3 gs(gsz(ctx->g_beam_setup, ctx->nb_beam_setup, side));
                 const bool boxes = ctx->n_boxes > 0 || ctx->env.box_kernels;
-                if (time_bs) HIP_TRY(ctx, hipEventRecord(ctx->prof_bs[2 * level], s_));      // the frame's dominant kernel on its own (bench.py: roofline)
                 if (lp.tiles) {
                     // candidates per (block, light) by binning; small flat kernels in front of the pairs' own pass
                     const dim3 gt((ctx->n_cu * 8 + 7) & ~7);       // (small kernels of few registers: they fit beside whatever else is resident)
                     hipLaunchKernelGGL(k_block_box, gt, block, 0, s_, ctx->S, lp, hb, bb, ctx->ctl);
                     hipLaunchKernelGGL(k_bin_zone, gt, block, 0, s_, ctx->S, ctx->F, lp, bb, ctx->ctl);
                     hipLaunchKernelGGL(k_bin_tiles, gt, block, 0, s_, ctx->S, ctx->F, lp, bb, ctx->ctl);
+                }
+                if (time_bs) HIP_TRY(ctx, hipEventRecord(ctx->prof_bs[2 * level], s_));      // the frame's dominant kernel on its own (bench.py: roofline)
+                if (lp.tiles) {
                     const dim3 gst(gsz(ctx->g_beam_setup_t, ctx->nb_beam_setup_t, side));
                     if (boxes) hipLaunchKernelGGL((k_beam_setup<false, true, true>), gst, block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);
                     else hipLaunchKernelGGL((k_beam_setup<false, false, true>), gst, block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, bb, ctx->ctl);

@@ -68,6 +68,26 @@ def test_full_frame_equals_the_exact_walk(bench_scene, full_frame):
     assert np.array_equal(full_frame["rgb8"], exact["rgb8"])
 
 
+def test_full_frame_takes_the_tile_beams_and_equals_the_pairs_own_walks(bench_scene, full_frame):
+    """At this size level 0 takes its candidates from the binned rows of its 8 x 8 pixel tiles; RT_FLAG_NO_TILES sends every
+    pair through the tree itself.  Same frame and counters; also at 3840x2160 (BASELINE.json configs[3], whole frame)."""
+    _, ctx = bench_scene
+    lib = native.lib()
+    n0 = lib.rt_debug_tile_frames(ctx._h)
+    again = ctx.render(params())
+    assert lib.rt_debug_tile_frames(ctx._h) == n0 + 1, "the full-size frame did not take the tile beams"
+    plain = ctx.render(params(flags=abi.RT_FLAG_NO_TILES))
+    assert lib.rt_debug_tile_frames(ctx._h) == n0 + 1
+    for out in (again, plain):
+        assert np.array_equal(out["ids"], full_frame["ids"]) and np.array_equal(out["rgb"], full_frame["rgb"])
+        assert out["stats"]["rays"] == full_frame["stats"]["rays"]
+    kw = dict(sh_rays=SH, rec_max=REC, jitter=True, seed=SEED + 1)
+    big = ctx.render(abi.render_params(3840, 2160, **kw), want_ids=False)
+    big_plain = ctx.render(abi.render_params(3840, 2160, flags=abi.RT_FLAG_NO_TILES, **kw), want_ids=False)
+    assert lib.rt_debug_tile_frames(ctx._h) == n0 + 2
+    assert np.array_equal(big["rgb"], big_plain["rgb"]) and big["stats"]["rays"] == big_plain["stats"]["rays"] > 1_000_000_000
+
+
 def test_eight_ranks_reassemble_the_full_frame(bench_scene, full_frame):
     _, ctx = bench_scene
     image = np.zeros((W * H, 3), dtype=np.uint8)
