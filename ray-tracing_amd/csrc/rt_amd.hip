@@ -2626,7 +2626,8 @@ static bool tile_scene_ok(const rt_ctx *ctx) { return ctx->F.ok && ctx->S.n_prim
 
 // Carve the state of a frame of `slots` primary slots with queue capacity `cap` into fs.  sets = 1..3 buffer sets (level 0 /
 // deeper levels odd / even); queues = 3 (levels in sequence) or 4 (pipelined deeper levels).  Nothing is initialised here.
-static int carve_frame(rt_ctx *ctx, Carver &mem, FrameState &fs, uint64_t slots, uint64_t cap0, uint64_t cap_deep, double qgrowth, int sets, int queues, bool tiles) {
+static int carve_frame(rt_ctx *ctx, Carver &mem, FrameState &fs, uint64_t slots, uint64_t cap0, uint64_t cap_deep, double qgrowth, int sets, int queues, bool tiles,
+                       uint64_t qbase0 = 0) {
 #define TRY_A(expr) do { int rc_ = (expr); if (rc_ != RT_OK) return rc_; } while (0)
     if (sets < 2) cap_deep = cap0;          // one set: every level lives in it
     auto qcap = [&](uint64_t c) { const double v = (double)c * qgrowth; return (uint32_t)(v < 2147483647.0 ? v : 2147483647.0); };
@@ -2640,10 +2641,11 @@ static int carve_frame(rt_ctx *ctx, Carver &mem, FrameState &fs, uint64_t slots,
     }
     for (int i = queues; i < 6; ++i) fs.q[i] = fs.q[queues - 1];
     const uint64_t nsl1 = (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1);
-    fs.beam_queue_cap = qcap(cap0);
+    if (!qbase0) qbase0 = cap0;             // the float64 queue of the first set: qgrowth entries per qbase0
+    fs.beam_queue_cap = qcap(qbase0);
     for (int set = 0; set < sets; ++set) {
         const uint64_t cap = set == 0 ? cap0 : cap_deep, nlit = cap * nsl1;
-        const uint32_t queue_cap = qcap(cap);
+        const uint32_t queue_cap = qcap(set == 0 ? qbase0 : cap);
         HitBuf &hb = *hit_set(fs, set);
         TRY_A(mem.get(&hb.px, cap)); TRY_A(mem.get(&hb.py, cap)); TRY_A(mem.get(&hb.pz, cap));
         TRY_A(mem.get(&hb.id, cap)); TRY_A(mem.get(&hb.list, cap));
@@ -2696,7 +2698,7 @@ static int init_frame_counters(rt_ctx *ctx, FrameState &fs, hipStream_t st) {
         HitBuf &hb = *hit_set(fs, set);
         BeamBuf &bb = *beam_set(fs, set);
         const uint64_t cap = set == 0 ? fs.cap : fs.cap_deep;
-        const double qd = (double)cap * fs.qgrowth_carved;
+        const double qd = set == 0 ? (double)fs.beam_queue_cap : (double)cap * fs.qgrowth_carved;
         HIP_TRY(ctx, hipMemsetAsync(hb.lit, 0, cap * nsl1 * sizeof(uint32_t), st));
         hipLaunchKernelGGL(k_init_beam_counters, dim3(1), dim3(64), 0, st, bb.queue_n, (uint32_t)(qd < 2147483647.0 ? qd : 2147483647.0));
     }
@@ -2706,12 +2708,16 @@ static int init_frame_counters(rt_ctx *ctx, FrameState &fs, hipStream_t st) {
 
 // (re)allocate queues for `slots` primary slots; only grows
 static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
-    uint64_t want_cap = (uint64_t)((double)slots * ctx->growth) + 1024;
-    if (want_cap > 0xFFFFFFF0ull) return fail(ctx, RT_ERR_UNSUPPORTED, "ray queue would exceed 2^32 entries");
-    const double want_qd = (double)want_cap * ctx->qgrowth;
+    // Level 0 holds the camera rays (or the caller's rays) and nothing else: its queue and buffer set are sized by the slots.  The
+    // levels >= 1 may hold up to `growth` rays per slot (two children per hit) and usually hold a fraction of one: their queues and
+    // sets start at growth / deep_div = 1 ray per slot; deep_div is halved, then growth doubled, when a level overflows.
+    const uint64_t want_full = (uint64_t)((double)slots * ctx->growth) + 1024;
+    if (want_full > 0xFFFFFFF0ull) return fail(ctx, RT_ERR_UNSUPPORTED, "ray queue would exceed 2^32 entries");
+    const double want_qd = (double)want_full * ctx->qgrowth;
     const uint32_t want_q = (uint32_t)(want_qd < 2147483647.0 ? want_qd : 2147483647.0);
-    // the levels >= 1 hold a fraction of the camera rays (deep_div starts at 2 and is halved when they overflow)
-    const uint64_t want_deep = std::min<uint64_t>(want_cap, (uint64_t)((double)want_cap / ctx->deep_div) + 1024);
+    const uint64_t want_deep = std::min<uint64_t>(want_full, (uint64_t)((double)want_full / ctx->deep_div) + 1024);
+    uint64_t want_cap = slots + 1024;
+    if (ctx->frame_bytes && !ctx->two_sets) want_cap = std::max(want_cap, want_deep);      // one buffer set: every level lives in it
     if (ctx->cap >= want_cap && ctx->cap_deep >= want_deep && ctx->fb_slots >= slots && ctx->beam_queue_cap >= want_q) {
         if (ctx->counters_dirty) {
             // the last frame was voided by a queue overflow: its shading kernels returned early and left lit counts behind
@@ -2726,7 +2732,7 @@ static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
     ctx->counters_dirty = false;
     HIP_TRY(ctx, hipDeviceSynchronize());   // rare: buffers of an in-flight frame are about to be replaced
     free_frame(ctx);
-    const uint64_t cap = want_cap;
+    uint64_t cap = slots + 1024;
     const uint64_t nsl1 = (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1);
     // Buffer sets two to five are speed-ups only (levels overlap; a level's buffers are reused two / four levels later): without
     // the memory for them levels share sets and run in sequence.
@@ -2734,7 +2740,7 @@ static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
     {
         size_t free_b = 0, total_b = 0;
         auto set_bytes = [&](uint64_t c) { return c * 40 + c * nsl1 * (4 + 72 + 16 * RT_PAIR_UNITS + 8 * (RT_BLOCK / 64) + 12) + (uint64_t)((double)c * ctx->qgrowth) * 8; };
-        const uint64_t queues_b = (cap + 5 * want_deep) * 84, fb_b = slots * 72;
+        const uint64_t queues_b = (cap + 5 * want_deep) * 84 + (uint64_t)want_qd * 8, fb_b = slots * 72;
         const uint64_t set0_b = set_bytes(cap), setd_b = set_bytes(want_deep);
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) sets = 1;
         else {
@@ -2746,10 +2752,11 @@ static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
         if (ctx->env_sets > 0 && ctx->env_sets < sets) sets = ctx->env_sets;      // RT_AMD_SETS = 1, 2, 3 or 5 / RT_AMD_ONE_SET (diagnostic)
         if (sets == 4) sets = 3;
     }
+    if (sets < 2) cap = std::max(cap, want_deep);        // one buffer set: every level lives in it
     Carver mem{ctx};
     FrameState fs;
     fs.ctl = ctx->ctl_own;
-    int rc = carve_frame(ctx, mem, fs, slots, cap, want_deep, ctx->qgrowth, sets, sets >= 5 ? 6 : 4, !ctx->env.no_tiles);
+    int rc = carve_frame(ctx, mem, fs, slots, cap, want_deep, ctx->qgrowth, sets, sets >= 5 ? 6 : 4, !ctx->env.no_tiles, want_full);
     if (rc == RT_OK) rc = init_frame_counters(ctx, fs, ctx->stream);
     if (rc == RT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, RT_ERR_HIP, "hipStreamSynchronize failed after frame set-up");
     if (rc != RT_OK) { free_frame(ctx); return rc; }
@@ -2886,7 +2893,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
     const uint32_t s2 = (uint32_t)(sh * sh);
     const bool beam = fast && ctx->S.n_planes <= RT_PMAX && !(p->flags & RT_FLAG_NO_BEAM) && s2 >= 9 && s2 <= RT_BLOCK &&
                       ctx->S.n_lights <= 256 &&   // pair record: 8-bit light index
-                      ctx->cap * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1) < (1ull << RT_LIST_NU_SHIFT);   // list entry: pair | units << 28
+                      std::max(ctx->cap, ctx->cap_deep) * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1) < (1ull << RT_LIST_NU_SHIFT);   // list entry: pair | units << 28
     // tile beams (level 0 of a camera frame in 8 x 8 tiles: the rays of a block of 64 slots are the pixels of a tile, their beams
     // towards a light nearly one beam); the binning buffers were carved for the frame sizes this context has seen
     if (beam && cam && cam->tw * cam->th == 64 && (long long)cam->n_slots >= ctx->env.tiles_min && !lp.beam_early && !ctx->env.no_tiles && !(p->flags & RT_FLAG_NO_TILES) && ctx->beam.trec != nullptr) {
@@ -3311,7 +3318,7 @@ extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
         if (!ctx->last_noalloc) ctx->counters_dirty = true;
         if (ctx->last_noalloc) return fail(ctx, RT_ERR_QUEUE_OVERFLOW, "secondary-ray queue overflow in a no-alloc frame (its queues hold 2 x the pixel slots and cannot grow); nothing valid was written");
         if (c.overflow_q && ctx->beam_queue_cap < 0x7fffffffu) ctx->qgrowth *= 8.0;
-        else if (c.overflow_deep && ctx->deep_div > 1.0 && ctx->cap_deep < ctx->cap) ctx->deep_div *= 0.5;
+        else if (c.overflow_deep && ctx->deep_div > 1.0) ctx->deep_div *= 0.5;
         else ctx->growth *= 2.0;
         return fail(ctx, RT_ERR_QUEUE_OVERFLOW, "secondary-ray queue overflow; queue growth factor doubled, render again");
     }
