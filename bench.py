@@ -49,7 +49,8 @@ def build_scene(workload, ingest="native", device=0):
     generated = {"synth10k": lambda: gen_scene.synth_spheres(100, 1234, 5, 5),
                  "synth400": lambda: gen_scene.synth_spheres(20, 1234, 5, 5),
                  "synth1M": lambda: gen_scene.synth_mixed(1000, 4321, 5, 10),    # BASELINE.json configs[4], R = 10
-                 "synth90k": lambda: gen_scene.synth_mixed(300, 4321, 5, 10)}
+                 "synth90k": lambda: gen_scene.synth_mixed(300, 4321, 5, 10),
+                 "synth10kmix": lambda: gen_scene.synth_mixed(100, 4321, 5, 10)}  # spheres and boxes at the size of the headline scene
     fixtures = {"pool": "pool.txt", "original": "original.txt"}
     tmp = None
     if workload in generated:

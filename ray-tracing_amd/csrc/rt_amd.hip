@@ -861,10 +861,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bin_tiles(DScene S, FastScene F, L
 template <bool EARLY, bool BOXES, bool TILES>
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) k_beam_setup(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb, BeamBuf bb,
                                                          FrameCtl *ctl) {
-    extern __shared__ uint2 lds_stack[];
+    extern __shared__ __align__(16) uint2 lds_stack[];
     __shared__ uint32_t lbuf_all[(RT_BLOCK / 64) * 128], obuf_all[(RT_BLOCK / 64) * 128];
     __shared__ uint32_t tl_all[RT_TOUCH * RT_BLOCK];     // [entry][lane]: touched leaf entries of the lane's traversal
-    __shared__ float4 rowbuf_all[TILES ? (RT_BLOCK / 64) * 2 * RT_TILE_NC : 1];      // per wave: the candidate row being filtered
     if (ctl->overflow) return;
     if (lp.prio) __builtin_amdgcn_s_setprio(3);
     const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
@@ -900,7 +899,10 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
             TileRow T;
             if (TILES) {
                 T.trec = bb.trec; T.tcnt = bb.tcnt; T.row = 0xffffffffu; T.lane = lane;
-                T.rowbuf = rowbuf_all + (threadIdx.x >> 6) * 2 * RT_TILE_NC;
+                // the row being filtered lives in the wave's columns of the first two stack rows (64 lanes x 8 bytes = 32 units each):
+                // the stack is empty until the walk of the pairs without a row starts, after the rows
+                T.rowbuf = (float4 *)(lds_stack + (threadIdx.x & ~63u));
+                T.rowbuf_hi = (float4 *)(lds_stack + RT_BLOCK + (threadIdx.x & ~63u)) - RT_TILE_NC;
                 T.pre_row = (uint32_t)__builtin_amdgcn_readfirstlane((int)((r >> 6) * nsl + ml));
                 T.pre = bb.trec[(uint64_t)T.pre_row * (2u * RT_TILE_NC) + (uint32_t)lane];
                 T.pre_cnt = bb.tcnt[T.pre_row];
@@ -1999,6 +2001,7 @@ struct EnvCfg {
     bool no_tiles = false;              // RT_AMD_NO_TILES: every pair walks the tree itself (no tile beams)
     long long tiles_min = 1500000;      // RT_AMD_TILES_MIN: tile beams for frames of at least this many camera rays (the three small
                                         // kernels in front of k_beam_setup cost more than they save on smaller frames)
+    int bin_wgs = 0;                    // RT_AMD_BIN_WGS: workgroups per CU of the binning kernels (default: by schedule and frame size)
     int tiles_min_prims = 1024;         // RT_AMD_TILES_MIN_PRIMS: ... in scenes of at least this many primitives (tile_scene_ok)
     bool one_shadow_stream = false;     // RT_AMD_ONE_SHADOW_STREAM: soft shadows of all deeper levels on stream3 (diagnostic)
     bool debug = false;                 // RT_AMD_DEBUG: per-level diagnostics on stderr
@@ -2014,6 +2017,7 @@ struct EnvCfg {
         no_tiles = getenv("RT_AMD_NO_TILES") != nullptr;
         if (const char *v = getenv("RT_AMD_TILES_MIN")) tiles_min = atoll(v);
         if (const char *v = getenv("RT_AMD_TILES_MIN_PRIMS")) tiles_min_prims = atoi(v);
+        if (const char *v = getenv("RT_AMD_BIN_WGS")) bin_wgs = std::max(1, std::min(16, atoi(v)));
         debug = getenv("RT_AMD_DEBUG") != nullptr;
         exact = getenv("RT_AMD_EXACT") != nullptr;
         if (const char *e = getenv("RT_AMD_OVL_MAIN")) ovl_main = atoi(e);
@@ -2414,7 +2418,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
         ctx->F.extent = ext * 1.000001f;
         ctx->F.depth = max_depth;
         ctx->F.ok = ok ? 1 : 0;
-        ctx->lds_bytes = ok ? (size_t)max_depth * RT_BLOCK * sizeof(uint2) : 0;
+        ctx->lds_bytes = ok ? (size_t)std::max(max_depth, 2) * RT_BLOCK * sizeof(uint2) : 0;     // (>= 2 rows: k_beam_setup stages tile rows there)
         if (ok) {
             // per-lane stacks can exceed the default 64 KB dynamic-LDS limit on deep trees
             const int big = 160 * 1024;
@@ -2428,9 +2432,8 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
             HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));
             HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));
             HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));
-            // + 4 KB: the candidate rows of the tile beams
-            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 20480));
-            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 20480));
+            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));
+            HIP_C(hipFuncSetAttribute((const void *)&k_beam_setup<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 16384));
             HIP_C(hipFuncSetAttribute((const void *)&k_intersect_only<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
             HIP_C(hipFuncSetAttribute((const void *)&k_visibility<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         }
@@ -2622,7 +2625,9 @@ struct Carver {
 // Tile beams pay in scenes whose tree takes a pair tens of node steps to walk and whose beams meet few primitives: measured
 // -6 % (1920x1080) to -16 % (3840x2160) on the 10 k lattice, +5 % on the 20-primitive pool scene (nothing to save there), no
 // change at 90 k primitives (half of the rows overflow).  A rule of the scene, like every other choice of kernels here.
-static bool tile_scene_ok(const rt_ctx *ctx) { return ctx->F.ok && ctx->S.n_prims >= ctx->env.tiles_min_prims && ctx->S.n_prims <= (int)RT_ZONE_NC; }
+static bool tile_scene_ok(const rt_ctx *ctx) {
+    return ctx->F.ok && ctx->S.n_prims >= ctx->env.tiles_min_prims && ctx->S.n_prims <= (int)RT_ZONE_NC;
+}
 
 // Carve the state of a frame of `slots` primary slots with queue capacity `cap` into fs.  sets = 1..3 buffer sets (level 0 /
 // deeper levels odd / even); queues = 3 (levels in sequence) or 4 (pipelined deeper levels).  Nothing is initialised here.
@@ -2936,7 +2941,13 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                 const bool boxes = ctx->n_boxes > 0 || ctx->env.box_kernels;
                 if (lp.tiles) {
                     // candidates per (block, light) by binning; small flat kernels in front of the pairs' own pass
-                    const dim3 gt((ctx->n_cu * 8 + 7) & ~7);       // (small kernels of few registers: they fit beside whatever else is resident)
+                    // Small kernels of few registers: 8 workgroups per CU fit.  In an overlapped frame they keep to the level-0 side's
+                    // share of the CUs all the same: the spawn and the first nearest-hit pass of the deeper levels start beside
+                    // them, and a CU full of binning workgroups makes that chain wait (measured, 3 against 8 per CU: 1920x1080
+                    // 1.67 / 1.74 ms, half of 3840x2160 2.82 / 2.97, a quarter 1.57 / 1.61; the whole 3840x2160 frame, where the
+                    // level-0 side is the long one, 5.45 / 5.38 - there they take the CUs).
+                    int bw = ctx->env.bin_wgs > 0 ? ctx->env.bin_wgs : ((overlap && side == 1 && ctx->fb_slots_frame <= (4u << 20)) ? ovl_main : 8);
+                    const dim3 gt((ctx->n_cu * bw + 7) & ~7);
                     hipLaunchKernelGGL(k_block_box, gt, block, 0, s_, ctx->S, lp, hb, bb, ctx->ctl);
                     hipLaunchKernelGGL(k_bin_zone, gt, block, 0, s_, ctx->S, ctx->F, lp, bb, ctx->ctl);
                     hipLaunchKernelGGL(k_bin_tiles, gt, block, 0, s_, ctx->S, ctx->F, lp, bb, ctx->ctl);

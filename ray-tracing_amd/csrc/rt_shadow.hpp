@@ -253,12 +253,13 @@ struct BeamOut {
 // TILES (k_beam_setup<.., true>, level 0): called by all 64 lanes of a wave together (on = false: the lane has no pair, or a
 // delicate one, and only helps staging); the lane's (block, light) row - trec / tcnt / row, row == 0xffffffff: none - lists the
 // primitives that the union of the block's beams can touch, and the lane keeps those its own beam can touch instead of walking
-// the tree.  rowbuf: the wave's LDS slice for one row (2 * RT_TILE_NC float4); pre_row / pre / pre_cnt: a row already in registers.
+// the tree.  rowbuf / rowbuf_hi: the wave's LDS slice for one row (2 * RT_TILE_NC float4, in two halves: the wave's columns of the
+// first two rows of the traversal stack, which is not in use while rows are filtered); pre_row / pre / pre_cnt: a row already in registers.
 struct TileRow {
     const float4 *__restrict__ trec;
     const uint32_t *__restrict__ tcnt;
     uint32_t row;
-    float4 *rowbuf;
+    float4 *rowbuf, *rowbuf_hi;       // units 0..RT_TILE_NC-1 / RT_TILE_NC..2*RT_TILE_NC-1 (rowbuf_hi is biased: index it with the unit number)
     int lane;
     uint32_t pre_row, pre_cnt;
     float4 pre;
@@ -328,7 +329,7 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
             if (dbg & 0x10000) cnt = 0u;                 // timing experiment only
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // earlier reads of the slice are done (WAR)
             __builtin_amdgcn_wave_barrier();
-            T->rowbuf[T->lane] = part;
+            (T->lane < (int)RT_TILE_NC ? T->rowbuf : T->rowbuf_hi)[T->lane] = part;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -336,7 +337,8 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
                 if (mine) use_walk = true;
             } else {
                 for (uint32_t j = 0; j < cnt; ++j) {
-                    const float4 ra = T->rowbuf[2u * j], rb4 = T->rowbuf[2u * j + 1u];
+                    const float4 *rw = 2u * j < RT_TILE_NC ? T->rowbuf : T->rowbuf_hi;
+                    const float4 ra = rw[2u * j], rb4 = rw[2u * j + 1u];
                     const uint32_t pk = __float_as_uint(rb4.w);
                     const bool sph = !BOXES || (pk & 3u) == 1u;     // sphere {centre, r, (low parts)}; box {lo, -, hi}
                     const float rr = sph ? ra.w : 0.0f;

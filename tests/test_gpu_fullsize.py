@@ -88,6 +88,24 @@ def test_full_frame_takes_the_tile_beams_and_equals_the_pairs_own_walks(bench_sc
     assert np.array_equal(big["rgb"], big_plain["rgb"]) and big["stats"]["rays"] == big_plain["stats"]["rays"] > 1_000_000_000
 
 
+def test_tile_beams_on_a_mixed_lattice_equal_the_pairs_own_walks():
+    """The box-capable template of the tile-beam set-up at a size where the default path takes it: 10 k spheres and boxes
+    with transparency and reflection (tools/gen_scene.synth_mixed(100)), 1920x1080, 5x5 shadow rays, recursion 10."""
+    sys.path.insert(0, ROOT)
+    import bench
+    scene, _ = bench.build_scene("synth10kmix")
+    with native.Context(scene.packed, device=0) as ctx:
+        kw = dict(sh_rays=5, rec_max=10, jitter=True, seed=77)
+        n0 = native.lib().rt_debug_tile_frames(ctx._h)
+        tiles = ctx.render(abi.render_params(W, H, **kw))
+        assert native.lib().rt_debug_tile_frames(ctx._h) == n0 + 1
+        plain = ctx.render(abi.render_params(W, H, flags=abi.RT_FLAG_NO_TILES, **kw))
+        assert np.array_equal(tiles["ids"], plain["ids"]) and np.array_equal(tiles["rgb"], plain["rgb"])
+        assert tiles["stats"]["rays"] == plain["stats"]["rays"] > 250_000_000
+        exact = ctx.render(abi.render_params(W, H, flags=abi.RT_FLAG_NO_BEAM, **kw))      # every shadow ray on its own, float64
+        assert np.array_equal(tiles["rgb"], exact["rgb"]) and tiles["stats"]["rays"] == exact["stats"]["rays"]
+
+
 def test_eight_ranks_reassemble_the_full_frame(bench_scene, full_frame):
     _, ctx = bench_scene
     image = np.zeros((W * H, 3), dtype=np.uint8)
