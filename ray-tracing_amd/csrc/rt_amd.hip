@@ -899,10 +899,10 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
             TileRow T;
             if (TILES) {
                 T.trec = bb.trec; T.tcnt = bb.tcnt; T.row = 0xffffffffu; T.lane = lane;
-                // the row being filtered lives in the wave's columns of the first two stack rows (64 lanes x 8 bytes = 32 units each):
+                // the half row being filtered lives in the wave's columns of the first two stack rows (64 lanes x 8 bytes = 32 units each):
                 // the stack is empty until the walk of the pairs without a row starts, after the rows
                 T.rowbuf = (float4 *)(lds_stack + (threadIdx.x & ~63u));
-                T.rowbuf_hi = (float4 *)(lds_stack + RT_BLOCK + (threadIdx.x & ~63u)) - RT_TILE_NC;
+                T.rowbuf_hi = (float4 *)(lds_stack + RT_BLOCK + (threadIdx.x & ~63u)) - RT_TILE_HALF;
                 T.pre_row = (uint32_t)__builtin_amdgcn_readfirstlane((int)((r >> 6) * nsl + ml));
                 T.pre = bb.trec[(uint64_t)T.pre_row * (2u * RT_TILE_NC) + (uint32_t)lane];
                 T.pre_cnt = bb.tcnt[T.pre_row];

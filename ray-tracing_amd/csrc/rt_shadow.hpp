@@ -57,7 +57,8 @@ struct BeamBuf {
     uint32_t *tcnt;          // [block * n_shadow_lights + light]: candidates in the row, or RT_TILE_OVERFLOW
     uint32_t *zlist, *zcnt;  // [zone * n_shadow_lights + light][min(n_prims, RT_ZONE_NC)]: canonical leaf entries of the primitives near the zone's union beam / their number
 };
-#define RT_TILE_NC 32u                  // candidates a (block, light) row holds: 1 KB, one float4 per lane of a wave
+#define RT_TILE_NC 64u                  // candidates a (block, light) row holds: 2 KB
+#define RT_TILE_HALF 32u                // ... and a wave stages at a time: 1 KB, one float4 per lane
 #define RT_REGION_NC 512u               // ... a (region, light) keeps in LDS
 #define RT_ZONE_NC 32768u               // ... a (zone, light) row (or every primitive of a smaller scene)
 #define RT_REGION_BLOCKS 16u            // a region = 4 x 4 blocks (32 x 32 pixels), a zone = 64 regions
@@ -259,7 +260,7 @@ struct TileRow {
     const float4 *__restrict__ trec;
     const uint32_t *__restrict__ tcnt;
     uint32_t row;
-    float4 *rowbuf, *rowbuf_hi;       // units 0..RT_TILE_NC-1 / RT_TILE_NC..2*RT_TILE_NC-1 (rowbuf_hi is biased: index it with the unit number)
+    float4 *rowbuf, *rowbuf_hi;       // units 0..RT_TILE_HALF-1 / RT_TILE_HALF..2*RT_TILE_HALF-1 of the staged half (rowbuf_hi is biased: index it with the unit number)
     int lane;
     uint32_t pre_row, pre_cnt;
     float4 pre;
@@ -329,15 +330,25 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
             if (dbg & 0x10000) cnt = 0u;                 // timing experiment only
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // earlier reads of the slice are done (WAR)
             __builtin_amdgcn_wave_barrier();
-            (T->lane < (int)RT_TILE_NC ? T->rowbuf : T->rowbuf_hi)[T->lane] = part;
+            (T->lane < (int)RT_TILE_HALF ? T->rowbuf : T->rowbuf_hi)[T->lane] = part;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (cnt == RT_TILE_OVERFLOW) {
                 if (mine) use_walk = true;
-            } else {
-                for (uint32_t j = 0; j < cnt; ++j) {
-                    const float4 *rw = 2u * j < RT_TILE_NC ? T->rowbuf : T->rowbuf_hi;
+            } else for (uint32_t half = 0; half * RT_TILE_HALF < cnt; ++half) {
+                if (half) {                              // (few rows are longer than one staged half: the second is fetched on demand)
+                    part = T->trec[(uint64_t)cur * (2u * RT_TILE_NC) + 2u * RT_TILE_HALF * half + (uint32_t)T->lane];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    (T->lane < (int)RT_TILE_HALF ? T->rowbuf : T->rowbuf_hi)[T->lane] = part;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
+                const uint32_t nh = min(cnt - half * RT_TILE_HALF, RT_TILE_HALF);
+                for (uint32_t j = 0; j < nh; ++j) {
+                    const float4 *rw = 2u * j < RT_TILE_HALF ? T->rowbuf : T->rowbuf_hi;
                     const float4 ra = rw[2u * j], rb4 = rw[2u * j + 1u];
                     const uint32_t pk = __float_as_uint(rb4.w);
                     const bool sph = !BOXES || (pk & 3u) == 1u;     // sphere {centre, r, (low parts)}; box {lo, -, hi}
