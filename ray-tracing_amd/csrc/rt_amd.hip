@@ -2622,11 +2622,13 @@ struct Carver {
     }
 };
 
-// Tile beams pay in scenes whose tree takes a pair tens of node steps to walk and whose beams meet few primitives: measured
-// -6 % (1920x1080) to -16 % (3840x2160) on the 10 k lattice, +5 % on the 20-primitive pool scene (nothing to save there), no
-// change at 90 k primitives (half of the rows overflow).  A rule of the scene, like every other choice of kernels here.
+// Tile beams pay in scenes whose tree takes a pair tens of node steps to walk: measured -11 % (1920x1080) to -16 % (3840x2160) on
+// the 10 k lattice, -6 % on the 90 k lattice (a sixth of its rows overflow), +5 % on the 20-primitive pool scene (nothing to save
+// there).  Scenes of >= 100 k primitives keep the walk with the umbra test inside it (lp.beam_early).  A rule of the scene, like
+// every other choice of kernels here.
 static bool tile_scene_ok(const rt_ctx *ctx) {
-    return ctx->F.ok && ctx->S.n_prims >= ctx->env.tiles_min_prims && ctx->S.n_prims <= (int)RT_ZONE_NC;
+    const bool long_beams = ctx->env.beam_early >= 0 ? ctx->env.beam_early != 0 : ctx->S.n_prims >= 100000;      // (lp.beam_early: the walk with the umbra test)
+    return ctx->F.ok && !long_beams && ctx->S.n_prims >= ctx->env.tiles_min_prims && ctx->S.n_prims <= (int)RT_ZONE_NC;
 }
 
 // Carve the state of a frame of `slots` primary slots with queue capacity `cap` into fs.  sets = 1..3 buffer sets (level 0 /

@@ -60,7 +60,7 @@ struct BeamBuf {
 #define RT_TILE_NC 64u                  // candidates a (block, light) row holds: 2 KB
 #define RT_TILE_HALF 32u                // ... and a wave stages at a time: 1 KB, one float4 per lane
 #define RT_REGION_NC 512u               // ... a (region, light) keeps in LDS
-#define RT_ZONE_NC 32768u               // ... a (zone, light) row (or every primitive of a smaller scene)
+#define RT_ZONE_NC 131072u              // ... a (zone, light) row (or every primitive of a smaller scene)
 #define RT_REGION_BLOCKS 16u            // a region = 4 x 4 blocks (32 x 32 pixels), a zone = 64 regions
 #define RT_TILE_OVERFLOW 0xFFFFFFFFu    // more candidates than the row holds: the pairs concerned walk the tree themselves
 #define RT_PAIR_LIT 0xFFFFFFFFu
