@@ -48,6 +48,7 @@ def build_scene(workload, ingest="native", device=0):
     from ray_tracing_amd.render import FastScene, Scene
     generated = {"synth10k": lambda: gen_scene.synth_spheres(100, 1234, 5, 5),
                  "synth400": lambda: gen_scene.synth_spheres(20, 1234, 5, 5),
+                 "synth100": lambda: gen_scene.synth_spheres(10, 1234, 5, 5),
                  "synth1M": lambda: gen_scene.synth_mixed(1000, 4321, 5, 10),    # BASELINE.json configs[4], R = 10
                  "synth90k": lambda: gen_scene.synth_mixed(300, 4321, 5, 10),
                  "synth10kmix": lambda: gen_scene.synth_mixed(100, 4321, 5, 10)}  # spheres and boxes at the size of the headline scene

@@ -2002,7 +2002,7 @@ struct EnvCfg {
     long long tiles_min = 1500000;      // RT_AMD_TILES_MIN: tile beams for frames of at least this many camera rays (the three small
                                         // kernels in front of k_beam_setup cost more than they save on smaller frames)
     int bin_wgs = 0;                    // RT_AMD_BIN_WGS: workgroups per CU of the binning kernels (default: by schedule and frame size)
-    int tiles_min_prims = 1024;         // RT_AMD_TILES_MIN_PRIMS: ... in scenes of at least this many primitives (tile_scene_ok)
+    int tiles_min_prims = 256;          // RT_AMD_TILES_MIN_PRIMS: ... in scenes of at least this many primitives (tile_scene_ok)
     bool one_shadow_stream = false;     // RT_AMD_ONE_SHADOW_STREAM: soft shadows of all deeper levels on stream3 (diagnostic)
     bool debug = false;                 // RT_AMD_DEBUG: per-level diagnostics on stderr
     bool exact = false;                 // RT_AMD_EXACT: batched queries through the reference-order walk
@@ -2624,7 +2624,7 @@ struct Carver {
 
 // Tile beams pay in scenes whose tree takes a pair tens of node steps to walk: measured -11 % (1920x1080) to -16 % (3840x2160) on
 // the 10 k lattice, -6 % on the 90 k lattice (a sixth of its rows overflow), +5 % on the 20-primitive pool scene (nothing to save
-// there).  Scenes of >= 100 k primitives keep the walk with the umbra test inside it (lp.beam_early).  A rule of the scene, like
+// there, break-even at 100 primitives, -7 % at 400 -> from 256 primitives on).  Scenes of >= 100 k primitives keep the walk with the umbra test inside it (lp.beam_early).  A rule of the scene, like
 // every other choice of kernels here.
 static bool tile_scene_ok(const rt_ctx *ctx) {
     const bool long_beams = ctx->env.beam_early >= 0 ? ctx->env.beam_early != 0 : ctx->S.n_prims >= 100000;      // (lp.beam_early: the walk with the umbra test)
