@@ -8,7 +8,9 @@
 //                  (level 0 also makes the camera rays, 8x8 pixel tile per wave)    (ray_functions.py:7-43,
 //                                                                                BSPNode.py:123-210)
 //     soft shadows (Light.py:178-288), rt_shadow.hpp:
-//       k_beam_setup   one lane per (hit, light) pair: one beam traversal for all its s*s rays, whole-pair verdicts
+//       k_block_box, k_bin_zone, k_bin_tiles   (level 0 of large frames) candidates per (8x8 pixel tile, light) by binning
+//       k_beam_setup   one lane per (hit, light) pair: one beam traversal for all its s*s rays - or the tile's candidate
+//                      row filtered - and whole-pair verdicts
 //       k_shadow_beam  one lane per ray of the pairs that need it: float32 filtered predicates on the pair's candidates
 //       k_shadow_walk  rays of pairs with too many candidates: each walks the tree itself, same predicates
 //       k_shadow_queue what the filters could not decide, in float64
@@ -18,8 +20,8 @@
 //                                                                               ray_tracer.py:77-132)
 //   k_resolve    clip + float32 / uint8 quantisation (k_accumulate: the same over K frames)
 //                                                                              (ray_tracer.py:30, util.py:98)
-// enqueue_levels() lays the levels out over three streams (level 0's shadows | nearest hits of levels 1.. | their
-// shadows and shading); DESIGN.md section 5 and 8.
+// enqueue_levels() lays the levels out over four streams (level 0's shadows | nearest hits of levels 1.. | their
+// shadows and shading, odd and even levels apart); DESIGN.md section 5 and 8.
 //
 // The colour recursion  colour = through*T + (diff+spec)*(1-T) + refl*Kr  is linear in the child
 // colours, so each queued ray carries a throughput and adds throughput*local to its pixel.
