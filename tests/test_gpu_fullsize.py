@@ -86,6 +86,11 @@ def test_full_frame_takes_the_tile_beams_and_equals_the_pairs_own_walks(bench_sc
     big_plain = ctx.render(abi.render_params(3840, 2160, flags=abi.RT_FLAG_NO_TILES, **kw), want_ids=False)
     assert lib.rt_debug_tile_frames(ctx._h) == n0 + 2
     assert np.array_equal(big["rgb"], big_plain["rgb"]) and big["stats"]["rays"] == big_plain["stats"]["rays"] > 1_000_000_000
+    # one of two ranks' share of that frame (8x8 tiles interleaved: a block's neighbours in slot order are two tiles apart)
+    half = ctx.render(abi.render_params(3840, 2160, rank=1, world=2, **kw), want_ids=False)
+    half_plain = ctx.render(abi.render_params(3840, 2160, rank=1, world=2, flags=abi.RT_FLAG_NO_TILES, **kw), want_ids=False)
+    assert lib.rt_debug_tile_frames(ctx._h) == n0 + 3
+    assert np.array_equal(half["rgb"], half_plain["rgb"]) and half["stats"]["rays"] == half_plain["stats"]["rays"]
 
 
 def test_tile_beams_on_a_mixed_lattice_equal_the_pairs_own_walks():
