@@ -230,6 +230,10 @@ int64_t rt_frame_bytes(const rt_ctx *ctx);
  *   queues hold 2 x the pixel slots and cannot grow: RT_ERR_QUEUE_OVERFLOW from rt_sync_stats is final for that frame.
  *   every call on a GPU uses that GPU's one array (whatever the context): calls that overlap on one GPU - two streams, two
  *     contexts, two threads - race; run them back to back on one stream or synchronise between them.
+ *   what the call enqueues besides kernels and memsets: the context's two timing events and one copy of the counter block to
+ *     pinned host memory, for rt_sync_stats.  rt_sync_stats describes a call that EXECUTED on its stream; for a call recorded
+ *     into a HIP graph the counters are those of the last replay that finished, ms_total is not available, and the library
+ *     has no test under capture (allocation-free is what is tested: rt_debug_alloc_calls unchanged, tests/test_zz_no_alloc.py).
  */
 int rt_render_device_noalloc(rt_ctx *ctx, const rt_render_params *p, float *d_rgb_out, uint8_t *d_rgb8_out,
                              int32_t *d_ids_out, void *stream);

@@ -268,6 +268,16 @@ struct ChunkWalk {
     }
 };
 
+// "A queue overflowed earlier in this frame: the frame is void" - read ONCE per workgroup and handed to all its waves, for the
+// kernels that hold workgroup barriers: another stream may raise the flag between the reads of two waves, and an exit that
+// splits a workgroup in front of a __syncthreads() must not depend on how this hardware treats ended waves at s_barrier.
+__device__ __forceinline__ bool frame_voided_uniform(const uint32_t *overflow_flag) {
+    __shared__ uint32_t voided_wg;
+    if (threadIdx.x == 0) voided_wg = *overflow_flag;
+    __syncthreads();
+    return voided_wg != 0u;
+}
+
 __device__ __forceinline__ void fb_add(double *fb, uint32_t slot, d3 c) {
     atomicAdd(fb + 3ull * slot + 0, c.x);
     atomicAdd(fb + 3ull * slot + 1, c.y);
@@ -335,12 +345,25 @@ __device__ __forceinline__ bool ray_is_tame(d3 o, d3 d) {
     return (m < 1e7) && (n < 1e7) && (n > 1e-30) && (d.x != 0) && (d.y != 0) && (d.z != 0);
 }
 
+#ifdef RT_TRAV_STATS
+// diagnostics build only (make stats): per level [rays, node steps, leaf visits, leaf batches, confirmations, max node steps, max leaf visits, max confirmations]
+__device__ unsigned long long g_trav_stats[RT_MAX_LEVELS * 8];
+__device__ unsigned long long g_trav_time[RT_MAX_LEVELS * 8];     // per level: max over waves of wall_clock64 ticks: [0] planes + root, [1] first pieces, [2] further pieces, [3] whole chunk, [4] pieces dealt (sum), [5] rounds (max), [6] exact walks (sum), [7] kernel (max over waves)
+#endif
 // nearest hit, fast path with exact fallback (ties between different primitives, wild rays, non-kd trees)
 template <bool FAST>
-__device__ __forceinline__ Hit nearest_hit(const DScene &S, const FastScene &F, uint2 *stk, d3 o, d3 d) {
+__device__ __forceinline__ Hit nearest_hit(const DScene &S, const FastScene &F, uint2 *stk, d3 o, d3 d, int stats_level = 0) {
     if (FAST && ray_is_tame(o, d)) {
         FastState st;
         fast_nearest<RT_BLOCK>(S, F, stk, o, d, __int_as_float(0x7f800000), -dinf(), st);
+#ifdef RT_TRAV_STATS
+        {
+            unsigned long long *ts = g_trav_stats + 8 * stats_level;
+            atomicAdd(ts + 0, 1ull); atomicAdd(ts + 1, (unsigned long long)st.n_node); atomicAdd(ts + 2, (unsigned long long)st.n_leaf);
+            atomicAdd(ts + 3, (unsigned long long)st.n_batch); atomicAdd(ts + 4, (unsigned long long)st.n_conf);
+            atomicMax(ts + 5, (unsigned long long)st.n_node); atomicMax(ts + 6, (unsigned long long)st.n_leaf); atomicMax(ts + 7, (unsigned long long)st.n_conf);
+        }
+#endif
         if (!st.tie) {
             if (st.best.id == 0 && S.far_clip)
                 st.best.p = mk3(RT_MAX_RENDER_DISTANCE, RT_MAX_RENDER_DISTANCE, RT_MAX_RENDER_DISTANCE);
@@ -420,164 +443,6 @@ __global__ void __launch_bounds__(RT_BLOCK) k_load_rays(const double *o, const d
     }
 }
 
-// GEN (level 0 of a frame): the camera rays are made here and written to the queue on the way - their stores
-// overlap the traversal instead of costing a launch of their own (k_gen) before it.
-template <bool FAST, bool GEN>
-__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) k_intersect(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb,
-                                                        FrameCtl *ctl, double *fb, int32_t *ids_out, GenParams gp, uint32_t *beam_counters,
-                                                        double *fb_side, double *fb_side2) {
-    extern __shared__ uint2 lds_stack[];
-    uint2 *stk = lds_stack + threadIdx.x;
-    if (ctl->overflow) return;                    // a queue overflowed earlier in this frame: the frame is void
-    // the level's soft-shadow kernels follow on this stream: their append counters start at zero (saves a memset launch)
-    if (beam_counters && blockIdx.x == 0 && threadIdx.x < 3) beam_counters[threadIdx.x] = 0u;
-    if (lp.prio) __builtin_amdgcn_s_setprio(3);
-    const uint32_t n = GEN ? gp.n_slots : min(ctl->n_rays[lp.level], lp.cap);
-    if (GEN && blockIdx.x == 0 && threadIdx.x == 0) ctl->n_rays[0] = gp.n_slots;
-    ChunkWalk walk(n);
-    uint64_t first;
-    const int lane = threadIdx.x & 63;
-    unsigned long long valid_total = 0;
-    __shared__ uint32_t hbuf_all[(RT_BLOCK / 64) * (RT_HIT_RUN + 64)];      // per wave: up to RT_HIT_RUN - 1 parked hits + the 64 of one more chunk
-    uint32_t *hbuf = hbuf_all + (threadIdx.x >> 6) * (RT_HIT_RUN + 64);
-    uint32_t hn = 0u;
-    __shared__ uint32_t wcnt[2][RT_BLOCK / 64], wbase[2];      // GEN = false: per-chunk hit counts of the waves (two chunks in flight)
-    uint32_t it = 0u;
-    while (walk.next(first)) {
-        uint64_t k = first + threadIdx.x;
-        bool active = k < n;
-        uint32_t slot = RT_INVALID_SLOT;
-        d3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
-        if (GEN) {
-            // every output slot is visited exactly once here: the framebuffers are initialised by plain stores
-            // (fb: 0 or the background of a miss, below; fb_side: 0) instead of two memsets before the frame
-            const bool in_range = active;
-            if (active) active = gen_ray<false>(gp, q, k, o, d, slot);
-            valid_total += active ? 1ull : 0ull;
-            const uint32_t zs = active ? slot : ((in_range && gp.world > 1) ? (uint32_t)k : RT_INVALID_SLOT);
-            if (zs != RT_INVALID_SLOT) {
-                if (!active) { fb[3ull * zs] = 0.0; fb[3ull * zs + 1] = 0.0; fb[3ull * zs + 2] = 0.0; }
-                if (fb_side) { fb_side[3ull * zs] = 0.0; fb_side[3ull * zs + 1] = 0.0; fb_side[3ull * zs + 2] = 0.0; }
-                if (fb_side2) { fb_side2[3ull * zs] = 0.0; fb_side2[3ull * zs + 1] = 0.0; fb_side2[3ull * zs + 2] = 0.0; }
-            }
-        } else {
-            slot = active ? q.slot[k] : RT_INVALID_SLOT;
-            active = active && slot != RT_INVALID_SLOT;
-            if (active) {
-                o = mk3(q.ox[k], q.oy[k], q.oz[k]);
-                d = mk3(q.dx[k], q.dy[k], q.dz[k]);
-            }
-        }
-        bool has_hit = false;
-        if (active) {
-            Hit h = nearest_hit<FAST>(S, F, stk, o, d);
-            if (ids_out && lp.level == 0) ids_out[slot] = h.id;
-            if (h.id == 0) {
-                // ray_tracer.py:65,72,132: misses keep the background colour
-                if (GEN) { fb[3ull * slot] = S.bg[0]; fb[3ull * slot + 1] = S.bg[1]; fb[3ull * slot + 2] = S.bg[2]; }   // = 0 + 1 * bg
-                else fb_add(fb, slot, mk3(q.tr[k], q.tg[k], q.tb[k]) * ld3(S.bg));
-            } else {
-                // (with side buffers the frame is an overlapped one: k_shade<.. | RT_SHADE_STORE> stores this slot's value later)
-                if (GEN && !fb_side) { fb[3ull * slot] = 0.0; fb[3ull * slot + 1] = 0.0; fb[3ull * slot + 2] = 0.0; }
-                hb.px[k] = h.p.x; hb.py[k] = h.p.y; hb.pz[k] = h.p.z;
-                hb.id[k] = h.id;
-                has_hit = true;
-            }
-        }
-        if (!has_hit && k < n) hb.id[k] = 0;      // (k_block_box reads the hit record of every slot)
-        // Compaction of the hit list.  The hits of a wave are parked in its LDS buffer and leave RT_HIT_RUN at a time: ONE
-        // returning atomic on the list counter per run.  (One per wave and chunk - 32 400 of them in a 1920x1080
-        // camera-ray pass, all on one address, ~12 ns each - was what the pass took, whatever the scene: 0.40 ms.)
-        // The deeper levels (GEN = false) hold few rays and run beside the level-0 kernels, where every KB of LDS counts:
-        // they append per chunk.
-        const unsigned long long mask = __ballot(has_hit);
-        if (!GEN) {
-            // one atomic per workgroup and chunk (the four waves' counts meet in LDS; every wave of a workgroup walks the
-            // same chunks, so the barriers are reached by all)
-            const uint32_t par = it & 1u, wv = threadIdx.x >> 6;
-            ++it;
-            if (lane == 0) wcnt[par][wv] = (uint32_t)__popcll(mask);
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const uint32_t tot = wcnt[par][0] + wcnt[par][1] + wcnt[par][2] + wcnt[par][3];
-                wbase[par] = tot ? atomicAdd(&ctl->n_hits[lp.level], tot) : 0u;
-            }
-            __syncthreads();
-            uint32_t base = wbase[par];
-            for (uint32_t w = 0; w < wv; ++w) base += wcnt[par][w];
-            if (has_hit) hb.list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)k;
-        } else if (mask) {
-            if (has_hit) hbuf[hn + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)k;
-            hn += (uint32_t)__popcll(mask);
-            if (hn >= RT_HIT_RUN) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&ctl->n_hits[lp.level], RT_HIT_RUN);
-                base = __shfl(base, 0);
-#pragma unroll
-                for (uint32_t j = 0; j < RT_HIT_RUN / 64u; ++j) hb.list[base + j * 64u + (uint32_t)lane] = hbuf[j * 64u + (uint32_t)lane];
-                const uint32_t rest = hbuf[RT_HIT_RUN + (uint32_t)lane];
-                hn -= RT_HIT_RUN;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                if ((uint32_t)lane < hn) hbuf[lane] = rest;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-    }
-    if (GEN && hn) {                              // the rest of the wave's hits
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&ctl->n_hits[lp.level], hn);
-        base = __shfl(base, 0);
-        for (uint32_t j = (uint32_t)lane; j < hn; j += 64u) hb.list[base + j] = hbuf[j];
-    }
-    if (GEN) {                                    // primary-ray count (padding lanes excluded)
-        for (int off = 32; off > 0; off >>= 1) valid_total += __shfl_down(valid_total, off);
-        if (lane == 0 && valid_total) atomicAdd(&ctl->primary_rays, valid_total);
-    }
-}
-
-// exact light-plane basis of one (hit, light) pair (Light.py:48-50,252-260)
-__device__ __forceinline__ void exact_basis(const DLight &Lt, int sh_rays, d3 P, d3 &up, d3 &right, d3 &p00) {
-    d3 lpos = ld3(Lt.pos);
-    d3 dl = lpos - P;                              // Light.py:48-50
-    d3 L = dl / norm3(dl);
-    light_basis(neg3(L), up, right);               // Light.py:257
-    double radius = Lt.radius;
-    double gsz = radius / (double)sh_rays;         // Light.py:254
-    double c0 = (radius - gsz) / 2;
-    p00 = (lpos + c0 * up) - c0 * right;           // Light.py:260
-}
-
-// NO_BEAM / exact modes: the float64 basis once per (hit, shadow light); k_shadow's s*s lanes of a pair reuse it
-__global__ void __launch_bounds__(RT_BLOCK) k_shadow_setup(DScene S, LevelParams lp, HitBuf hb, SegBuf sg, FrameCtl *ctl) {
-    if (ctl->overflow) return;
-    if (lp.prio) __builtin_amdgcn_s_setprio(3);
-    const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
-    const uint32_t nsl = (uint32_t)S.n_shadow_lights;
-    const uint64_t total = (uint64_t)n_hits * nsl;
-    ChunkWalk walk(total);
-    uint64_t first;
-    while (walk.next(first)) {
-        uint64_t seg = first + threadIdx.x;
-        if (seg >= total) continue;
-        uint32_t h = (uint32_t)(seg / nsl), ml = (uint32_t)(seg % nsl);
-        uint32_t r = hb.list[h];
-        d3 P = mk3(hb.px[r], hb.py[r], hb.pz[r]);
-        d3 up, right, p00;
-        exact_basis(S.lights[S.shadow_lights[ml]], lp.sh_rays, P, up, right, p00);
-        sg.ux[seg] = up.x; sg.uy[seg] = up.y; sg.uz[seg] = up.z;
-        sg.rx[seg] = right.x; sg.ry[seg] = right.y; sg.rz[seg] = right.z;
-        sg.cx[seg] = p00.x; sg.cy[seg] = p00.y; sg.cz[seg] = p00.z;
-    }
-}
-
 // Wave-private append: values are parked in the wave's LDS buffer (128 entries) and get their slots 64 at a time -
 // ONE returning atomic on the counter per 64 values (returning atomics on a single address complete at ~30 ns
 // each; one per wave and chunk was the bottleneck of the kernels that append).  All 64 lanes call these together.
@@ -614,6 +479,428 @@ __device__ __forceinline__ void wave_append_flush(T *buf, uint32_t n, uint32_t *
     if (lane == 0) base = atomicAdd(counter, n);
     base = __shfl(base, 0);
     if ((uint32_t)lane < n) store(base + (uint32_t)lane, buf[lane]);
+}
+
+// Children of the level's hits (ray_tracer.py:108-130), made by the nearest-hit kernel itself: the next level's query is the
+// frame's longest dependency chain (hits(L) -> children -> hits(L + 1) -> ...), and a launch of its own per level for the
+// children - over EVERY hit, to find the few whose material spawns - sat in the middle of it.  A lane that finds a hit on a
+// spawning surface parks (queue index of the parent << 1 | kind) in the wave's LDS buffer; 64 parked entries leave together:
+// ONE returning atomic on the next queue's tail, then every lane makes one child from its parent's records (direction, hit
+// point, id, throughput, keys - written by this wave earlier in the kernel, hence the fences) - dense work for all 64 lanes.
+// kind 0: straight through (T != 0), kind 1: mirror (|Kr| != 0).
+struct ChildOut { uint32_t n_refl, n_trans; };      // per lane and kernel: < 2^32
+__device__ __forceinline__ void spawn_children(const DScene &S, const LevelParams &lp, const RayQ &q, const RayQ &qn, const HitBuf &hb, FrameCtl *ctl,
+                                               const uint32_t *cbuf, uint32_t count, int lane, bool unit_thr, ChildOut &co) {
+    // the parents' records were stored by other lanes of THIS wave: workgroup scope orders them with the loads below (one CU, one
+    // vector L1, write-through) - a wider scope would write back and invalidate L2 lines of everything running on the XCD
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&ctl->n_rays[lp.level + 1], count);
+    base = __shfl(base, 0);
+    if (base + count > lp.cap_next) {
+        if (lane == 0) ctl->overflow = ctl->overflow_deep = 1;     // frame is invalid; host re-renders with larger queues
+        return;
+    }
+    if ((uint32_t)lane >= count) return;
+    const uint32_t e = cbuf[lane], k = e >> 1;
+    const bool mirror = (e & 1u) != 0u;
+    const d3 d = mk3(q.dx[k], q.dy[k], q.dz[k]);
+    const d3 P = mk3(hb.px[k], hb.py[k], hb.pz[k]);
+    d3 thr = mk3(1.0, 1.0, 1.0);
+    if (!unit_thr) thr = mk3(q.tr[k], q.tg[k], q.tb[k]);
+    int32_t mi;
+    const d3 N = surface_normal(S, hb.id[k], P, mi);                 // ray_tracer.py:77-78
+    const DMat &M = S.mats[(mi >= 0 && mi < S.n_mats) ? mi : 0];     // (a parked entry has a valid material: its flags were read)
+    const uint32_t w = base + (uint32_t)lane;
+    d3 o_c, d_c, thr_c;
+    if (!mirror) {                                                   // ray_tracer.py:108-116
+        const double T = M.T;
+        thr_c = thr * mk3(T, T, T);
+        d_c = d;
+        o_c = P + RT_EPSILON * d;
+        co.n_trans++;
+    } else {                                                         // ray_tracer.py:119-129
+        thr_c = thr * ld3(M.kr);
+        const d3 V = neg3(d);
+        const d3 Nh = N / norm3(N);                                  // ray_functions.py:98-99
+        const double dp = dot3(V, Nh);
+        d_c = (2 * dp) * Nh - V;                                     // ray_functions.py:103
+        o_c = P + RT_EPSILON * d_c;
+        co.n_refl++;
+    }
+    qn.ox[w] = o_c.x; qn.oy[w] = o_c.y; qn.oz[w] = o_c.z;
+    qn.dx[w] = d_c.x; qn.dy[w] = d_c.y; qn.dz[w] = d_c.z;
+    qn.tr[w] = thr_c.x; qn.tg[w] = thr_c.y; qn.tb[w] = thr_c.z;
+    qn.slot[w] = q.slot[k]; qn.gpix[w] = q.gpix[k]; qn.path[w] = child_path(q.path[k], mirror ? 1u : 0u);
+}
+
+// what the camera-ray pass writes for the tile beams of its level (k_block_box's work, folded in: a wave of the pass IS a
+// block of 64 ray slots and holds its hit points in registers): the blocks' boxes, and the zones' list counters cleared
+struct TileOut {
+    float *blockbox;         // nullptr: no tile beams in this frame
+    uint32_t *zcnt;
+    uint32_t zrows;
+};
+
+#define RT_SEG_MAX 16u        // pieces a long ray is cut into at most (k_intersect)
+__device__ __forceinline__ float seg_start(float rmin, float seg, uint32_t k) { return fmaf((float)k, seg, rmin); }
+
+// Nearest hit of every queued ray; miss -> background, hit -> hit record + compacted hit list + the hit's children appended to
+// the next level's queue.
+// GEN (level 0 of a frame): the camera rays are made here and written to the queue on the way - their stores
+// overlap the traversal instead of costing a launch of their own (k_gen) before it.
+// !GEN, long rays in pieces: a level >= 1 holds few rays, some of them long (a reflection skimming over the field crosses 60
+// leaves where the average ray crosses 3), and the kernel lasts as long as its longest lane.  A ray's part inside the root box
+// is cut into K <= RT_SEG_MAX pieces of F.seg_len; lane = ray walks the first piece, and the pieces still needed afterwards
+// (those that start before the best hit so far) are dealt to the lanes of the wave, 64 at a time, each walked like a ray of
+// its own - any sub-range of the ray parameter may be walked separately, fast_tree tests every primitive of a visited leaf
+// whole - and merged back by their ray's lane: strictly smaller float64 distance wins, equal distances of different
+// primitives (and ties inside a piece) send the ray to the reference-order walk, as in nearest_hit.
+template <bool FAST, bool GEN, bool SEG = false>
+__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) k_intersect(DScene S, FastScene F, LevelParams lp, RayQ q, RayQ qn, HitBuf hb,
+                                                        FrameCtl *ctl, double *fb, int32_t *ids_out, GenParams gp, uint32_t *beam_counters,
+                                                        double *fb_side, double *fb_side2, TileOut to) {
+    extern __shared__ uint2 lds_stack[];
+    uint2 *stk = lds_stack + threadIdx.x;
+#ifdef RT_TRAV_STATS
+    const long long tk0 = wall_clock64();
+#endif
+    if (frame_voided_uniform(&ctl->overflow)) return;       // a queue overflowed earlier in this frame: the frame is void
+    // the level's soft-shadow kernels follow on this stream: their append counters start at zero (saves a memset launch)
+    if (beam_counters && blockIdx.x == 0 && threadIdx.x < 3) beam_counters[threadIdx.x] = 0u;
+    if (GEN && to.blockbox && blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < to.zrows; i += RT_BLOCK) to.zcnt[i] = 0u;
+    if (lp.prio) __builtin_amdgcn_s_setprio(3);
+    const uint32_t n = GEN ? gp.n_slots : min(ctl->n_rays[lp.level], lp.cap);
+    if (GEN && blockIdx.x == 0 && threadIdx.x == 0) ctl->n_rays[0] = gp.n_slots;
+    ChunkWalk walk(n);
+    uint64_t first;
+    const int lane = threadIdx.x & 63;
+    unsigned long long valid_total = 0;
+    // Compaction of the hit list.  The hits of a wave are parked in its LDS buffer and leave HRUN at a time: ONE returning
+    // atomic on the list counter per run.  (One per wave and chunk - 32 400 of them in a 1920x1080 camera-ray pass, all on
+    // one address, ~12 ns each - was what the pass took, whatever the scene: 0.40 ms.)  The deeper levels hold few rays and
+    // run beside the level-0 kernels, where every KB of LDS counts: runs of 64 there.
+    constexpr uint32_t HRUN = GEN ? RT_HIT_RUN : 64u;
+    __shared__ uint32_t hbuf_all[(RT_BLOCK / 64) * (HRUN + 64)];      // per wave: up to HRUN - 1 parked hits + the 64 of one more chunk
+    uint32_t *hbuf = hbuf_all + (threadIdx.x >> 6) * (HRUN + 64);
+    uint32_t hn = 0u;
+    __shared__ uint32_t cbuf_all[(RT_BLOCK / 64) * 192];              // per wave: parked children (<= 63 + 2 x 64)
+    uint32_t *cbuf = cbuf_all + (threadIdx.x >> 6) * 192;
+    uint32_t cn = 0u;
+    ChildOut co;
+    co.n_refl = 0; co.n_trans = 0;
+    const bool unit_thr = GEN || (lp.unit_thr && lp.level == 0);
+    for (;;) {
+      const bool more = walk.next(first);
+      if (more) {
+        uint64_t k = first + threadIdx.x;
+        bool active = k < n;
+        uint32_t slot = RT_INVALID_SLOT;
+        d3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
+        if (GEN) {
+            // every output slot is visited exactly once here: the framebuffers are initialised by plain stores
+            // (fb: 0 or the background of a miss, below; fb_side: 0) instead of two memsets before the frame
+            const bool in_range = active;
+            if (active) active = gen_ray<false>(gp, q, k, o, d, slot);
+            valid_total += active ? 1ull : 0ull;
+            const uint32_t zs = active ? slot : ((in_range && gp.world > 1) ? (uint32_t)k : RT_INVALID_SLOT);
+            if (zs != RT_INVALID_SLOT) {
+                if (!active) { fb[3ull * zs] = 0.0; fb[3ull * zs + 1] = 0.0; fb[3ull * zs + 2] = 0.0; }
+                if (fb_side) { fb_side[3ull * zs] = 0.0; fb_side[3ull * zs + 1] = 0.0; fb_side[3ull * zs + 2] = 0.0; }
+                if (fb_side2) { fb_side2[3ull * zs] = 0.0; fb_side2[3ull * zs + 1] = 0.0; fb_side2[3ull * zs + 2] = 0.0; }
+            }
+        } else {
+            slot = active ? q.slot[k] : RT_INVALID_SLOT;
+            active = active && slot != RT_INVALID_SLOT;
+            if (active) {
+                o = mk3(q.ox[k], q.oy[k], q.oz[k]);
+                d = mk3(q.dx[k], q.dy[k], q.dz[k]);
+            }
+        }
+        // the nearest hit; hid: its id, hp: its point (also stored to the hit record as soon as it is known)
+        int32_t hid = 0;
+        d3 hp = mk3(dnan(), dnan(), dnan());
+        if (FAST && !GEN && SEG) {
+            // ---- long rays in pieces (all 64 lanes stay together: the pieces are dealt with wave shuffles).  Registers are the
+            // limit here (128, so that a workgroup of this kernel fits beside three of the level-0 side): a ray's origin and
+            // direction are read again from the queue where they are needed after the walk, and the hit point of the best
+            // hit so far lives in the hit record, not in registers
+            const float inf = __int_as_float(0x7f800000);
+            const bool tame = active && ray_is_tame(o, d);
+            const bool exact = active && !tame;
+#ifdef RT_TRAV_STATS
+            const long long tc0 = wall_clock64();
+#endif
+            FastState acc;
+            fast_init(acc, inf);
+            float rmin = 0.0f, rmax = -1.0f, seg = 0.0f;
+            uint32_t K = 0u;
+            if (tame) {
+                const FastRay R0 = fast_ray(F, o, d);
+                fast_planes(S, R0, o, d, -dinf(), acc);
+                if (fast_root_interval(F, R0, acc.tbest, rmin, rmax)) {
+                    const float pieces = ceilf((rmax - rmin) * R0.dnf * F.inv_seg_len);
+                    K = pieces >= 2.0f ? (pieces < (float)RT_SEG_MAX ? (uint32_t)pieces : RT_SEG_MAX) : 1u;      // (NaN: 1 piece)
+                    seg = (rmax - rmin) / (float)K;
+                    if (!(seg > 0.0f) || !(seg < inf)) K = 1u;
+                }
+            }
+#ifdef RT_TRAV_STATS
+            const long long tc1 = wall_clock64();
+#endif
+            // round 0: the lane's own ray, first piece
+            if (K > 0u) {
+                const FastRay R = fast_ray(F, o, d);
+                fast_tree<RT_BLOCK>(S, F, stk, R, o, d, rmin, K > 1u ? seg_start(rmin, seg, 1u) : rmax, -dinf(), acc);
+            }
+            if (acc.best.id != 0) { hb.px[k] = acc.best.p.x; hb.py[k] = acc.best.p.y; hb.pz[k] = acc.best.p.z; }
+            double best_dist = acc.best.dist;
+            int32_t best_id = acc.best.id;
+            float best_tb = acc.tbest;
+            bool tie = acc.tie;
+            // pieces 1 .. K - 1 that start before the best hit so far (one too many is harmless: it ends at once)
+            uint32_t n_extra = 0u;
+            if (K > 1u) {
+                const float cap = fminf(rmax, best_tb);
+                if (cap > seg_start(rmin, seg, 1u)) {
+                    const float kf = floorf((cap - rmin) / seg) + 1.0f;
+                    n_extra = kf < (float)(K - 1u) ? (uint32_t)kf : K - 1u;
+                }
+            }
+            uint32_t incl = n_extra;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t v = (uint32_t)__shfl_up((int)incl, off);
+                if (lane >= off) incl += v;
+            }
+            const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+#ifdef RT_TRAV_STATS
+            const long long tc2 = wall_clock64();
+#endif
+            for (uint32_t base = 0u; base < total; base += 64u) {
+                // this lane's piece: piece `kseg` of the ray of lane `src`
+                const uint32_t item = base + (uint32_t)lane;
+                const bool have = item < total;
+                int src = 0;                         // number of lanes whose inclusive count is <= item
+                for (int step = 32; step >= 1; step >>= 1) {
+                    const uint32_t v = (uint32_t)__shfl((int)incl, src + step - 1);
+                    if (v <= item) src += step;
+                }
+                src &= 63;
+                const uint32_t s_incl = (uint32_t)__shfl((int)incl, src), s_extra = (uint32_t)__shfl((int)n_extra, src), s_K = (uint32_t)__shfl((int)K, src);
+                const uint32_t kseg = item - (s_incl - s_extra) + 1u;
+                const float s_rmin = __shfl(rmin, src), s_rmax = __shfl(rmax, src), s_seg = __shfl(seg, src);
+                const float tb = __shfl(best_tb, src);
+                const float t0 = seg_start(s_rmin, s_seg, kseg);
+                const float t1 = kseg + 1u >= s_K ? s_rmax : seg_start(s_rmin, s_seg, kseg + 1u);
+                // the ray itself: straight from the queue (the source lane's registers do not keep it)
+                const uint32_t s_k = (uint32_t)__shfl((int)(uint32_t)k, src);
+                FastState st;
+                fast_init(st, tb);
+                if (have) {
+                    const d3 io = mk3(q.ox[s_k], q.oy[s_k], q.oz[s_k]), idv = mk3(q.dx[s_k], q.dy[s_k], q.dz[s_k]);
+                    const FastRay R = fast_ray(F, io, idv);
+                    fast_tree<RT_BLOCK>(S, F, stk, R, io, idv, t0, t1, -dinf(), st);
+                }
+                // merge: the pieces of this lane's ray sit in lanes [a, a + run) of this round
+                const uint32_t excl = incl - n_extra;
+                const uint32_t lo = excl > base ? excl : base, hi = incl < base + 64u ? incl : base + 64u;
+                const uint32_t run = hi > lo ? hi - lo : 0u, a = lo - base;
+                int win = -1;
+                for (uint32_t jj = 0; __any(jj < run); ++jj) {
+                    const int idx = (int)((a + jj) & 63u);
+                    const double dj = __shfl(st.best.dist, idx);
+                    const int idj = __shfl(st.best.id, idx), tiej = __shfl((int)st.tie, idx);
+                    const float tbj = __shfl(st.tbest, idx);
+                    if (jj < run) {
+                        if (tiej) tie = true;
+                        if (dj < best_dist) { best_dist = dj; best_id = idj; best_tb = tbj; win = idx; }
+                        else if (dj == best_dist && idj != best_id && idj != 0) tie = true;
+                    }
+                }
+                const int wl = win >= 0 ? win : 0;
+                const double wx = __shfl(st.best.p.x, wl), wy = __shfl(st.best.p.y, wl), wz = __shfl(st.best.p.z, wl);
+                if (win >= 0) { hb.px[k] = wx; hb.py[k] = wy; hb.pz[k] = wz; }
+            }
+#ifdef RT_TRAV_STATS
+            {
+                const long long tc3 = wall_clock64();
+                unsigned long long *tt = g_trav_time + 8 * lp.level;
+                if (lane == 0) {
+                    atomicMax(tt + 0, (unsigned long long)(tc1 - tc0)); atomicMax(tt + 1, (unsigned long long)(tc2 - tc1)); atomicMax(tt + 2, (unsigned long long)(tc3 - tc2));
+                    atomicAdd(tt + 4, (unsigned long long)total); atomicMax(tt + 5, (unsigned long long)((total + 63u) / 64u));
+                }
+                if (active && (exact || tie)) atomicAdd(tt + 6, 1ull);
+            }
+#endif
+            if (active) {
+                hid = best_id;
+                if (exact || tie) {
+                    const Hit h = nearest_hit_exact(S, mk3(q.ox[k], q.oy[k], q.oz[k]), mk3(q.dx[k], q.dy[k], q.dz[k]));
+                    hid = h.id;
+                    if (hid != 0) { hb.px[k] = h.p.x; hb.py[k] = h.p.y; hb.pz[k] = h.p.z; }
+                }
+            }
+        } else if (active) {
+            const Hit h = nearest_hit<FAST>(S, F, stk, o, d, lp.level);
+            hid = h.id;
+            hp = h.p;
+            if (hid != 0) { hb.px[k] = hp.x; hb.py[k] = hp.y; hb.pz[k] = hp.z; }
+        }
+        bool has_hit = false;
+        uint32_t mflags = 0u;
+        if (active) {
+            if (ids_out && lp.level == 0) ids_out[slot] = hid;
+            if (hid == 0) {
+                // ray_tracer.py:65,72,132: misses keep the background colour
+                if (GEN) { fb[3ull * slot] = S.bg[0]; fb[3ull * slot + 1] = S.bg[1]; fb[3ull * slot + 2] = S.bg[2]; }   // = 0 + 1 * bg
+                else fb_add(fb, slot, mk3(q.tr[k], q.tg[k], q.tb[k]) * ld3(S.bg));
+            } else {
+                // (with side buffers the frame is an overlapped one: k_shade<.. | RT_SHADE_STORE> stores this slot's value later)
+                if (GEN && !fb_side) { fb[3ull * slot] = 0.0; fb[3ull * slot + 1] = 0.0; fb[3ull * slot + 2] = 0.0; }
+                hb.id[k] = hid;
+                has_hit = true;
+                // does the material spawn?  (SurfaceAbs.py:61,83 look the surface up by LIST POSITION = hit id, Q8: an id past the
+                // list reads as material 0, like surface_normal)
+                if (!lp.last_level) mflags = (uint32_t)((hid > 0 && hid < S.n_surfs) ? S.surfs[hid].mflags : (S.n_mats > 0 ? S.mats[0].flags : 0));
+            }
+        }
+        if (!GEN && !has_hit && k < n) hb.id[k] = 0;      // (k_block_box reads the hit record of every slot)
+        if (GEN && to.blockbox) {
+            // box of the block's hit points, rounded outward (a wave of the camera pass = one block of 64 ray slots)
+            const float inf = __int_as_float(0x7f800000);
+            float b0 = inf, b1 = inf, b2 = inf, B0 = -inf, B1 = -inf, B2 = -inf;
+            if (has_hit) {
+                b0 = __double2float_rd(hp.x); b1 = __double2float_rd(hp.y); b2 = __double2float_rd(hp.z);
+                B0 = __double2float_ru(hp.x); B1 = __double2float_ru(hp.y); B2 = __double2float_ru(hp.z);
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                b0 = fminf(b0, __shfl_xor(b0, off)); b1 = fminf(b1, __shfl_xor(b1, off)); b2 = fminf(b2, __shfl_xor(b2, off));
+                B0 = fmaxf(B0, __shfl_xor(B0, off)); B1 = fmaxf(B1, __shfl_xor(B1, off)); B2 = fmaxf(B2, __shfl_xor(B2, off));
+            }
+            if (lane == 0 && k < n) {
+                float4 *bx = (float4 *)(to.blockbox + 8ull * (k >> 6));
+                bx[0] = make_float4(b0, b1, b2, 0.0f);
+                bx[1] = make_float4(B0, B1, B2, 0.0f);
+            }
+        }
+        // ---- the hit list ----
+        const unsigned long long mask = __ballot(has_hit);
+        if (mask) {
+            if (has_hit) hbuf[hn + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)k;
+            hn += (uint32_t)__popcll(mask);
+            if (hn >= HRUN) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&ctl->n_hits[lp.level], HRUN);
+                base = __shfl(base, 0);
+#pragma unroll
+                for (uint32_t j = 0; j < HRUN / 64u; ++j) hb.list[base + j * 64u + (uint32_t)lane] = hbuf[j * 64u + (uint32_t)lane];
+                const uint32_t rest = hbuf[HRUN + (uint32_t)lane];
+                hn -= HRUN;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                if ((uint32_t)lane < hn) hbuf[lane] = rest;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        // ---- the children: parked ----
+        {
+            const uint32_t nc = (mflags & 1u) + ((mflags >> 1) & 1u);
+            const unsigned long long m1 = __ballot(nc >= 1u), m2 = __ballot(nc == 2u);
+            if (m1) {
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const uint32_t pos = cn + (uint32_t)__popcll(m1 & below) + (uint32_t)__popcll(m2 & below);
+                if (nc >= 1u) cbuf[pos] = ((uint32_t)k << 1) | ((mflags & 1u) ? 0u : 1u);     // through first, like ray_tracer.py:108-129
+                if (nc == 2u) cbuf[pos + 1u] = ((uint32_t)k << 1) | 1u;
+                cn += (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
+            }
+        }
+      }
+      // ---- 64 parked children leave together (at the end: the rest) ----
+      while (cn >= 64u || (!more && cn > 0u)) {
+          const uint32_t count = cn < 64u ? cn : 64u;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          spawn_children(S, lp, q, qn, hb, ctl, cbuf, count, lane, unit_thr, co);
+          const uint32_t v1 = cbuf[64 + lane], v2 = cbuf[128 + lane];
+          cn -= count;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+          cbuf[lane] = v1; cbuf[64 + lane] = v2;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+      }
+      if (!more) break;
+    }
+    if (hn) {                                     // the rest of the wave's hits
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&ctl->n_hits[lp.level], hn);
+        base = __shfl(base, 0);
+        for (uint32_t j = (uint32_t)lane; j < hn; j += 64u) hb.list[base + j] = hbuf[j];
+    }
+    {
+        unsigned long long n_refl = co.n_refl, n_trans = co.n_trans;
+        for (int off = 32; off > 0; off >>= 1) {
+            n_refl += __shfl_down(n_refl, off);
+            n_trans += __shfl_down(n_trans, off);
+        }
+        if (lane == 0) {
+            if (n_refl) atomicAdd(&ctl->reflect_rays, n_refl);
+            if (n_trans) atomicAdd(&ctl->transmit_rays, n_trans);
+        }
+    }
+    if (GEN) {                                    // primary-ray count (padding lanes excluded)
+        for (int off = 32; off > 0; off >>= 1) valid_total += __shfl_down(valid_total, off);
+        if (lane == 0 && valid_total) atomicAdd(&ctl->primary_rays, valid_total);
+    }
+#ifdef RT_TRAV_STATS
+    if (lane == 0) atomicMax(g_trav_time + 8 * lp.level + 7, (unsigned long long)(wall_clock64() - tk0));
+#endif
+}
+
+// exact light-plane basis of one (hit, light) pair (Light.py:48-50,252-260)
+__device__ __forceinline__ void exact_basis(const DLight &Lt, int sh_rays, d3 P, d3 &up, d3 &right, d3 &p00) {
+    d3 lpos = ld3(Lt.pos);
+    d3 dl = lpos - P;                              // Light.py:48-50
+    d3 L = dl / norm3(dl);
+    light_basis(neg3(L), up, right);               // Light.py:257
+    double radius = Lt.radius;
+    double gsz = radius / (double)sh_rays;         // Light.py:254
+    double c0 = (radius - gsz) / 2;
+    p00 = (lpos + c0 * up) - c0 * right;           // Light.py:260
+}
+
+// NO_BEAM / exact modes: the float64 basis once per (hit, shadow light); k_shadow's s*s lanes of a pair reuse it
+__global__ void __launch_bounds__(RT_BLOCK) k_shadow_setup(DScene S, LevelParams lp, HitBuf hb, SegBuf sg, FrameCtl *ctl) {
+    if (ctl->overflow) return;
+    if (lp.prio) __builtin_amdgcn_s_setprio(3);
+    const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
+    const uint32_t nsl = (uint32_t)S.n_shadow_lights;
+    const uint64_t total = (uint64_t)n_hits * nsl;
+    ChunkWalk walk(total);
+    uint64_t first;
+    while (walk.next(first)) {
+        uint64_t seg = first + threadIdx.x;
+        if (seg >= total) continue;
+        uint32_t h = (uint32_t)(seg / nsl), ml = (uint32_t)(seg % nsl);
+        uint32_t r = hb.list[h];
+        d3 P = mk3(hb.px[r], hb.py[r], hb.pz[r]);
+        d3 up, right, p00;
+        exact_basis(S.lights[S.shadow_lights[ml]], lp.sh_rays, P, up, right, p00);
+        sg.ux[seg] = up.x; sg.uy[seg] = up.y; sg.uz[seg] = up.z;
+        sg.rx[seg] = right.x; sg.ry[seg] = right.y; sg.rz[seg] = right.z;
+        sg.cx[seg] = p00.x; sg.cy[seg] = p00.y; sg.cz[seg] = p00.z;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -680,7 +967,7 @@ __device__ __forceinline__ void wave_union_box(const float *blockbox, uint32_t c
 
 // zones: every primitive against the union beam of each (zone, light); work item = (row, group of 8 chunks of RT_BLOCK primitives)
 __global__ void __launch_bounds__(RT_BLOCK) k_bin_zone(DScene S, FastScene F, LevelParams lp, BeamBuf bb, FrameCtl *ctl) {
-    if (ctl->overflow) return;
+    if (frame_voided_uniform(&ctl->overflow)) return;
     const uint32_t n = min(ctl->n_rays[lp.level], lp.cap);
     const TileGrid G(n, lp.tile_stride);
     const uint32_t nsl = (uint32_t)S.n_shadow_lights, np = (uint32_t)S.n_prims, zcap = min(np, RT_ZONE_NC);
@@ -742,7 +1029,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bin_zone(DScene S, FastScene F, Le
 __global__ void __launch_bounds__(RT_BLOCK) k_bin_tiles(DScene S, FastScene F, LevelParams lp, BeamBuf bb, FrameCtl *ctl) {
     __shared__ uint32_t cnt;
     __shared__ float4 recs[2 * RT_REGION_NC];
-    if (ctl->overflow) return;
+    if (frame_voided_uniform(&ctl->overflow)) return;
     const uint32_t n = min(ctl->n_rays[lp.level], lp.cap);
     const TileGrid G(n, lp.tile_stride);
     const uint32_t nsl = (uint32_t)S.n_shadow_lights, zcap = min((uint32_t)S.n_prims, RT_ZONE_NC), rows = G.nreg * nsl;
@@ -1447,7 +1734,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_queue(DScene S, FastScene F
     const uint32_t n = min(bb.queue_n[0], bb.queue_n[3]);
     const uint32_t s2 = (uint32_t)(lp.sh_rays * lp.sh_rays);
     const uint64_t n_ovf = (uint64_t)bb.queue_n[2] * s2;
-    const uint64_t total = (uint64_t)n + (n_ovf < (uint64_t)lp.walk_min ? n_ovf : 0ull);   // else k_shadow_walk has dealt with them
+    // walk_min == 0xffffffff: k_shadow_walk was not launched at all (a rule of the scene, enqueue_levels) - every such ray is
+    // taken here, however many there are; else k_shadow_walk has dealt with them from walk_min rays on
+    const bool take_ovf = lp.walk_min == 0xffffffffu || n_ovf < (uint64_t)lp.walk_min;
+    const uint64_t total = (uint64_t)n + (take_ovf ? n_ovf : 0ull);
     ChunkWalk walk(total);
     uint64_t first;
     while (walk.next(first)) {
@@ -1464,167 +1754,100 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_queue(DScene S, FastScene F
     }
 }
 
-// Phong shading (MODE & 1) + secondary-ray generation (MODE & 2) for every hit of the level.  The two halves are
-// separate launches at level 0 when the frame overlaps its levels: the children only need the hit, not the
-// lit counts, so level 1 can start while level 0's soft shadows are still being decided.
+// Phong shading for every hit of the level (the children are made by k_intersect).
 #define RT_SHADE_LIGHTS 1
-#define RT_SHADE_SPAWN 2
 #define RT_SHADE_STORE 4     // level 0 of a frame: fb is this pass's own buffer and holds 0 at every hit's slot (k_intersect's
                              // camera-ray pass), one hit per slot - a plain store replaces three float64 atomics per hit
+// fbc: where the background goes that the children of the LAST level's hits would return (ray_tracer.py:62-63)
 template <int MODE>
-__global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, LevelParams lp, RayQ q, RayQ qn, HitBuf hb, FrameCtl *ctl,
-                                                    double *fb, const unsigned long long *litbits, const uint32_t *pair_slot, const uint32_t *queue_n) {
+__global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, LevelParams lp, RayQ q, HitBuf hb, FrameCtl *ctl,
+                                                    double *fb, double *fbc, const unsigned long long *litbits, const uint32_t *pair_slot, const uint32_t *queue_n) {
     if (ctl->overflow) return;
     if (lp.prio) __builtin_amdgcn_s_setprio(3);
-    if ((MODE & RT_SHADE_LIGHTS) && lp.beam && blockIdx.x == 0 && threadIdx.x == 0) { ctl->n_queued[lp.level] = queue_n[0]; ctl->n_listed[lp.level] = queue_n[1]; ctl->n_walked[lp.level] = queue_n[2] * (uint32_t)(lp.sh_rays * lp.sh_rays); }
+    if (lp.beam && blockIdx.x == 0 && threadIdx.x == 0) { ctl->n_queued[lp.level] = queue_n[0]; ctl->n_listed[lp.level] = queue_n[1]; ctl->n_walked[lp.level] = queue_n[2] * (uint32_t)(lp.sh_rays * lp.sh_rays); }
     const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
     const uint32_t nsl = (uint32_t)S.n_shadow_lights;
     const double s2 = (double)(lp.sh_rays * lp.sh_rays);
     ChunkWalk walk(n_hits);
     uint64_t first;
-    const int lane = threadIdx.x & 63;
-    unsigned long long n_refl = 0, n_trans = 0;
     while (walk.next(first)) {
         uint64_t h = first + threadIdx.x;
-        bool active = h < n_hits;
-        int n_child = 0;
-        d3 o_t, d_t, thr_t, o_r, d_r, thr_r;
-        bool want_t = false, want_r = false;
-        uint32_t slot = 0, gpix = 0, path = 0;
-        if (active) {
-            uint32_t r = hb.list[h];
-            d3 d = mk3(q.dx[r], q.dy[r], q.dz[r]);
-            d3 thr = mk3(1.0, 1.0, 1.0);
-            if (!(lp.unit_thr && lp.level == 0)) thr = mk3(q.tr[r], q.tg[r], q.tb[r]);
-            d3 P = mk3(hb.px[r], hb.py[r], hb.pz[r]);
-            slot = q.slot[r]; gpix = q.gpix[r]; path = q.path[r];
-            int32_t id = hb.id[r], mi;
-            d3 N = surface_normal(S, id, P, mi);                         // ray_tracer.py:77-78
-            d3 Kd = mk3(0, 0, 0), Ks = mk3(0, 0, 0), Kr = mk3(0, 0, 0);
-            double T = 0;
-            int32_t phong = 0, mflags = 0;
-            if (mi >= 0 && mi < S.n_mats) {                              // Material.py:23-62
-                const DMat &M = S.mats[mi];
-                Kd = ld3(M.kd); Ks = ld3(M.ks); Kr = ld3(M.kr);
-                T = M.T; phong = M.phong; mflags = M.flags;
-            }
-            d3 V = neg3(d);
-            d3 Nh = N / norm3(N);                                        // ray_functions.py:98-99
-            d3 diff = mk3(0, 0, 0), spec = mk3(0, 0, 0);
-            uint32_t ml = 0;
-            for (int m = 0; (MODE & RT_SHADE_LIGHTS) && m < S.n_lights; ++m) {
-                const DLight &Lt = S.lights[m];
-                d3 dl = ld3(Lt.pos) - P;                                 // Light.py:35-53
-                d3 L = dl / norm3(dl);
-                double I = 1.0;                                          // Light.py:199-200
-                if (Lt.shadow != 0) {
-                    uint64_t seg = (uint64_t)h * nsl + ml;
-                    uint32_t cnt = hb.lit[seg];
-                    hb.lit[seg] = 0;                                     // ready for the next level
-                    if (lp.beam) {                                       // + the beam path's verdicts
-                        const uint32_t ps = pair_slot[(uint64_t)ml * lp.cap + h];
-                        const uint32_t ss = (uint32_t)(lp.sh_rays * lp.sh_rays);
-                        if (ps == RT_PAIR_LIT) cnt += ss;
-                        else if (ps != RT_PAIR_UNLIT) {                  // listed: lanes [lo, lo + s*s) of the slot's chunk
-                            const uint32_t chunk = ps / lp.spb, sib = ps - chunk * lp.spb;
-                            const uint32_t lo = sib * ss, hi = lo + ss;
-                            const unsigned long long *bits = litbits + (uint64_t)chunk * (RT_BLOCK / 64);
-                            for (uint32_t w = lo >> 6; w <= ((hi - 1u) >> 6); ++w) {
-                                const uint32_t b0 = w << 6;
-                                const uint32_t l = lo > b0 ? lo - b0 : 0u, u = hi < b0 + 64u ? hi - b0 : 64u;   // bit range [l, u) of word w
-                                const unsigned long long m = (u == 64u ? ~0ull : ((1ull << u) - 1ull)) & ~((1ull << l) - 1ull);
-                                cnt += (uint32_t)__popcll(bits[w] & m);
-                            }
+        if (h >= n_hits) continue;
+        uint32_t r = hb.list[h];
+        d3 d = mk3(q.dx[r], q.dy[r], q.dz[r]);
+        d3 thr = mk3(1.0, 1.0, 1.0);
+        if (!(lp.unit_thr && lp.level == 0)) thr = mk3(q.tr[r], q.tg[r], q.tb[r]);
+        d3 P = mk3(hb.px[r], hb.py[r], hb.pz[r]);
+        const uint32_t slot = q.slot[r];
+        int32_t id = hb.id[r], mi;
+        d3 N = surface_normal(S, id, P, mi);                         // ray_tracer.py:77-78
+        d3 Kd = mk3(0, 0, 0), Ks = mk3(0, 0, 0), Kr = mk3(0, 0, 0);
+        double T = 0;
+        int32_t phong = 0, mflags = 0;
+        if (mi >= 0 && mi < S.n_mats) {                              // Material.py:23-62
+            const DMat &M = S.mats[mi];
+            Kd = ld3(M.kd); Ks = ld3(M.ks); Kr = ld3(M.kr);
+            T = M.T; phong = M.phong; mflags = M.flags;
+        }
+        d3 V = neg3(d);
+        d3 Nh = N / norm3(N);                                        // ray_functions.py:98-99
+        d3 diff = mk3(0, 0, 0), spec = mk3(0, 0, 0);
+        uint32_t ml = 0;
+        for (int m = 0; m < S.n_lights; ++m) {
+            const DLight &Lt = S.lights[m];
+            d3 dl = ld3(Lt.pos) - P;                                 // Light.py:35-53
+            d3 L = dl / norm3(dl);
+            double I = 1.0;                                          // Light.py:199-200
+            if (Lt.shadow != 0) {
+                uint64_t seg = (uint64_t)h * nsl + ml;
+                uint32_t cnt = hb.lit[seg];
+                hb.lit[seg] = 0;                                     // ready for the next level
+                if (lp.beam) {                                       // + the beam path's verdicts
+                    const uint32_t ps = pair_slot[(uint64_t)ml * lp.cap + h];
+                    const uint32_t ss = (uint32_t)(lp.sh_rays * lp.sh_rays);
+                    if (ps == RT_PAIR_LIT) cnt += ss;
+                    else if (ps != RT_PAIR_UNLIT) {                  // listed: lanes [lo, lo + s*s) of the slot's chunk
+                        const uint32_t chunk = ps / lp.spb, sib = ps - chunk * lp.spb;
+                        const uint32_t lo = sib * ss, hi = lo + ss;
+                        const unsigned long long *bits = litbits + (uint64_t)chunk * (RT_BLOCK / 64);
+                        for (uint32_t w = lo >> 6; w <= ((hi - 1u) >> 6); ++w) {
+                            const uint32_t b0 = w << 6;
+                            const uint32_t l = lo > b0 ? lo - b0 : 0u, u = hi < b0 + 64u ? hi - b0 : 64u;   // bit range [l, u) of word w
+                            const unsigned long long m = (u == 64u ? ~0ull : ((1ull << u) - 1ull)) & ~((1ull << l) - 1ull);
+                            cnt += (uint32_t)__popcll(bits[w] & m);
                         }
                     }
-                    ml++;
-                    double frac = (double)cnt / s2;                  // Light.py:223
-                    I = (1.0 - Lt.shadow) + Lt.shadow * frac;            // Light.py:226
                 }
-                I = I < 0 ? 0 : (I > 1 ? 1 : I);                         // Light.py:84
-                d3 col = ld3(Lt.color);
-                d3 Ims = (Lt.spec * I) * col;                            // Light.py:87
-                d3 Imd = I * col;                                        // Light.py:91
-                double ldn = dot3(L, N);                                 // Light.py:123-125
-                ldn = isnan(ldn) ? ldn : (ldn > 0 ? ldn : 0);
-                d3 dterm = (ldn * Kd) * Imd;
-                diff = (m == 0) ? dterm : diff + dterm;
-                double dp = dot3(L, Nh);                                 // ray_functions.py:101-103
-                d3 R = (2 * dp) * Nh - L;
-                double rv = dot3(R, V);                                  // Light.py:169
-                double pw = ipow(rv, phong);
-                d3 sterm = (pw * Ks) * Ims;                              // Light.py:171
-                spec = (m == 0) ? sterm : spec + sterm;
+                ml++;
+                double frac = (double)cnt / s2;                  // Light.py:223
+                I = (1.0 - Lt.shadow) + Lt.shadow * frac;            // Light.py:226
             }
-            spec = mk3(nan_to_num(spec.x), nan_to_num(spec.y), nan_to_num(spec.z));   // Light.py:173
-            double nt = 1.0 - T;
-            d3 base = (diff + spec) * mk3(nt, nt, nt);                   // ray_tracer.py:105-106
-            if (MODE & RT_SHADE_STORE) {
-                const d3 v = thr * base;
-                fb[3ull * slot] = v.x; fb[3ull * slot + 1] = v.y; fb[3ull * slot + 2] = v.z;
-            } else if (MODE & RT_SHADE_LIGHTS) fb_add(fb, slot, thr * base);
-            if (!(MODE & RT_SHADE_SPAWN)) mflags = 0;
-            if (mflags & 1) {                                            // ray_tracer.py:108-116
-                thr_t = thr * mk3(T, T, T);
-                if (lp.last_level) fb_add(fb, slot, thr_t * ld3(S.bg));  // child returns background (:62-63)
-                else {
-                    want_t = true;
-                    d_t = d;
-                    o_t = P + RT_EPSILON * d;
-                }
-            }
-            if (mflags & 2) {                                            // ray_tracer.py:119-129
-                thr_r = thr * Kr;
-                if (lp.last_level) fb_add(fb, slot, thr_r * ld3(S.bg));
-                else {
-                    want_r = true;
-                    double dp = dot3(V, Nh);
-                    d_r = (2 * dp) * Nh - V;                             // ray_functions.py:103
-                    o_r = P + RT_EPSILON * d_r;
-                }
-            }
-            n_child = (want_t ? 1 : 0) + (want_r ? 1 : 0);
+            I = I < 0 ? 0 : (I > 1 ? 1 : I);                         // Light.py:84
+            d3 col = ld3(Lt.color);
+            d3 Ims = (Lt.spec * I) * col;                            // Light.py:87
+            d3 Imd = I * col;                                        // Light.py:91
+            double ldn = dot3(L, N);                                 // Light.py:123-125
+            ldn = isnan(ldn) ? ldn : (ldn > 0 ? ldn : 0);
+            d3 dterm = (ldn * Kd) * Imd;
+            diff = (m == 0) ? dterm : diff + dterm;
+            double dp = dot3(L, Nh);                                 // ray_functions.py:101-103
+            d3 R = (2 * dp) * Nh - L;
+            double rv = dot3(R, V);                                  // Light.py:169
+            double pw = ipow(rv, phong);
+            d3 sterm = (pw * Ks) * Ims;                              // Light.py:171
+            spec = (m == 0) ? sterm : spec + sterm;
         }
-        // wave-level exclusive prefix sum of n_child -> one atomic per wave on the next queue's tail
-        int incl = n_child;
-        for (int off = 1; off < 64; off <<= 1) {
-            int v = __shfl_up(incl, off);
-            if (lane >= off) incl += v;
+        spec = mk3(nan_to_num(spec.x), nan_to_num(spec.y), nan_to_num(spec.z));   // Light.py:173
+        double nt = 1.0 - T;
+        d3 base = (diff + spec) * mk3(nt, nt, nt);                   // ray_tracer.py:105-106
+        if (MODE & RT_SHADE_STORE) {
+            const d3 v = thr * base;
+            fb[3ull * slot] = v.x; fb[3ull * slot + 1] = v.y; fb[3ull * slot + 2] = v.z;
+        } else fb_add(fb, slot, thr * base);
+        if (lp.last_level) {                                         // the children would return the background (ray_tracer.py:62-63)
+            if (mflags & 1) fb_add(fbc, slot, (thr * mk3(T, T, T)) * ld3(S.bg));      // ray_tracer.py:108-116
+            if (mflags & 2) fb_add(fbc, slot, (thr * Kr) * ld3(S.bg));                // ray_tracer.py:119-129
         }
-        int total = __shfl(incl, 63);
-        if (total) {
-            uint32_t base = 0;
-            if (lane == 63) base = atomicAdd(&ctl->n_rays[lp.level + 1], (uint32_t)total);
-            base = __shfl(base, 63);
-            uint32_t w = base + (uint32_t)(incl - n_child);
-            if (base + (uint32_t)total > lp.cap_next) {
-                if (lane == 63) ctl->overflow = ctl->overflow_deep = 1;     // frame is invalid; host re-renders with larger queues
-            } else {
-                if (want_t) {
-                    qn.ox[w] = o_t.x; qn.oy[w] = o_t.y; qn.oz[w] = o_t.z;
-                    qn.dx[w] = d_t.x; qn.dy[w] = d_t.y; qn.dz[w] = d_t.z;
-                    qn.tr[w] = thr_t.x; qn.tg[w] = thr_t.y; qn.tb[w] = thr_t.z;
-                    qn.slot[w] = slot; qn.gpix[w] = gpix; qn.path[w] = path * 2u;
-                    w++;
-                    n_trans++;
-                }
-                if (want_r) {
-                    qn.ox[w] = o_r.x; qn.oy[w] = o_r.y; qn.oz[w] = o_r.z;
-                    qn.dx[w] = d_r.x; qn.dy[w] = d_r.y; qn.dz[w] = d_r.z;
-                    qn.tr[w] = thr_r.x; qn.tg[w] = thr_r.y; qn.tb[w] = thr_r.z;
-                    qn.slot[w] = slot; qn.gpix[w] = gpix; qn.path[w] = path * 2u + 1u;
-                    n_refl++;
-                }
-            }
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        n_refl += __shfl_down(n_refl, off);
-        n_trans += __shfl_down(n_trans, off);
-    }
-    if (lane == 0) {
-        if (n_refl) atomicAdd(&ctl->reflect_rays, n_refl);
-        if (n_trans) atomicAdd(&ctl->transmit_rays, n_trans);
     }
 }
 
@@ -2131,6 +2354,23 @@ static int scratch_address(rt_ctx *ctx, int device, unsigned char **out) {
 }
 
 extern "C" int64_t rt_debug_alloc_calls(void) { return (int64_t)g_alloc_calls.load(); }
+#ifdef RT_TRAV_STATS
+// diagnostics build only: copy out (and clear) the traversal counters, 8 per level
+extern "C" int rt_debug_trav_stats(unsigned long long *out, int n) {
+    if (hipDeviceSynchronize() != hipSuccess) return RT_ERR_HIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trav_stats), (size_t)n * sizeof(unsigned long long)) != hipSuccess) return RT_ERR_HIP;
+    static unsigned long long zero[RT_MAX_LEVELS * 8];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_trav_stats), zero, sizeof(zero)) != hipSuccess) return RT_ERR_HIP;
+    return RT_OK;
+}
+extern "C" int rt_debug_trav_time(unsigned long long *out, int n) {
+    if (hipDeviceSynchronize() != hipSuccess) return RT_ERR_HIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trav_time), (size_t)n * sizeof(unsigned long long)) != hipSuccess) return RT_ERR_HIP;
+    static unsigned long long zero[RT_MAX_LEVELS * 8];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_trav_time), zero, sizeof(zero)) != hipSuccess) return RT_ERR_HIP;
+    return RT_OK;
+}
+#endif
 extern "C" int64_t rt_debug_tile_frames(const rt_ctx *ctx) { return ctx ? ctx->tile_frames : 0; }
 extern "C" int64_t rt_noalloc_scratch_bytes(void) { return (int64_t)RT_SCRATCH_BYTES; }
 
@@ -2418,14 +2658,28 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
             ext = fmaxf(ext, fmaxf(fabsf(ctx->F.root_lo[k]), fabsf(ctx->F.root_hi[k])));
         }
         ctx->F.extent = ext * 1.000001f;
+        {
+            // pieces of long rays (k_intersect): RT_AMD_SEG_LEAVES (default 8, 0 = never cut) times the edge of a cube that holds
+            // one leaf's share of the root box - what a ray crosses per leaf, roughly
+            double vol = 1.0;
+            for (int k = 0; k < 3; ++k) vol *= std::max(s->node_hi[k] - s->node_lo[k], 1e-30);
+            int n_leaves = 0;
+            for (int i = 0; i < nn; ++i) n_leaves += s->node_right[i] < 0 ? 1 : 0;
+            const double leaf_edge = cbrt(vol / (double)std::max(n_leaves, 1));
+            double per = 0.0;
+            if (const char *e = getenv("RT_AMD_SEG_LEAVES")) per = atof(e);
+            const double seg_len = per * leaf_edge;
+            ctx->F.inv_seg_len = (per > 0.0 && seg_len > 0.0 && std::isfinite(seg_len)) ? (float)(1.0 / seg_len) : 0.0f;
+        }
         ctx->F.depth = max_depth;
         ctx->F.ok = ok ? 1 : 0;
         ctx->lds_bytes = ok ? (size_t)std::max(max_depth, 2) * RT_BLOCK * sizeof(uint2) : 0;     // (>= 2 rows: k_beam_setup stages tile rows there)
         if (ok) {
             // per-lane stacks can exceed the default 64 KB dynamic-LDS limit on deep trees
             const int big = 160 * 1024;
-            HIP_C(hipFuncSetAttribute((const void *)&k_intersect<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 1024));   // 40 B of static LDS
-            HIP_C(hipFuncSetAttribute((const void *)&k_intersect<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 8192));   // 5 KB of static LDS (hit buffer)
+            HIP_C(hipFuncSetAttribute((const void *)&k_intersect<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 8192));   // 5 KB of static LDS (hit and child buffers)
+            HIP_C(hipFuncSetAttribute((const void *)&k_intersect<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 8192));
+            HIP_C(hipFuncSetAttribute((const void *)&k_intersect<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 12288));   // 8 KB of static LDS (hit and child buffers)
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow_queue, hipFuncAttributeMaxDynamicSharedMemorySize, big));
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow_walk, hipFuncAttributeMaxDynamicSharedMemorySize, big - 8192));   // 4 KB of static LDS (queue buffer)
@@ -2467,7 +2721,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
         ctx->g_beam = grid_for((const void *)&k_shadow_beam, 0); ctx->nb_beam = last_nb;
         ctx->g_queue = grid_for((const void *)&k_shadow_queue, lds); ctx->nb_queue = last_nb;
         ctx->g_walk = grid_for((const void *)&k_shadow_walk, lds); ctx->nb_walk = last_nb;
-        ctx->g_shade = grid_for((const void *)&k_shade<3>, 0); ctx->nb_shade = last_nb;
+        ctx->g_shade = grid_for((const void *)&k_shade<RT_SHADE_LIGHTS>, 0); ctx->nb_shade = last_nb;
         ctx->g_setup = grid_for((const void *)&k_shadow_setup, 0); ctx->nb_setup = last_nb;
         if (getenv("RT_AMD_DEBUG"))
             fprintf(stderr, "[rt_amd] grids: intersect %d beam_setup %d beam %d queue %d shade %d\n", ctx->g_intersect,
@@ -2482,19 +2736,6 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
         planes[i].d = s->pln_d[i]; planes[i].id = s->pln_id[i]; planes[i].pad = 0;
     }
     TRY_C(upload(ctx, ctx->scene_allocs, planes, &ctx->S.planes));
-    std::vector<DSurf> surfs(s->n_surfaces);
-    parallel_for((size_t)s->n_surfaces, [&](size_t b0, size_t e0) {
-        for (size_t i = b0; i < e0; ++i) {
-            DSurf &d = surfs[i];
-            memset(&d, 0, sizeof(d));
-            d.kind = s->surf_kind[i]; d.mat = s->surf_mat[i];
-            const size_t g = (size_t)s->surf_geom[i];
-            if (d.kind == RT_SURF_SPHERE) for (int k = 0; k < 3; ++k) d.p[k] = s->sph_center[3 * g + k];
-            if (d.kind == RT_SURF_BOX) { for (int k = 0; k < 3; ++k) d.p[k] = s->box_center[3 * g + k]; d.p[3] = s->box_scale[g]; }
-            if (d.kind == RT_SURF_PLANE) for (int k = 0; k < 3; ++k) d.p[k] = s->pln_normal[3 * g + k];
-        }
-    });
-    TRY_C(upload(ctx, ctx->scene_allocs, surfs, &ctx->S.surfs));
     std::vector<DMat> mats(s->n_materials);
     for (int i = 0; i < s->n_materials; ++i) {
         DMat &m = mats[i];
@@ -2505,6 +2746,20 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
         double nk = sqrt((m.kr[0] * m.kr[0] + m.kr[1] * m.kr[1]) + m.kr[2] * m.kr[2]);
         m.flags = (m.T != 0 ? 1 : 0) | (nk != 0 ? 2 : 0);
     }
+    std::vector<DSurf> surfs(s->n_surfaces);
+    parallel_for((size_t)s->n_surfaces, [&](size_t b0, size_t e0) {
+        for (size_t i = b0; i < e0; ++i) {
+            DSurf &d = surfs[i];
+            memset(&d, 0, sizeof(d));
+            d.kind = s->surf_kind[i]; d.mat = s->surf_mat[i];
+            d.mflags = (d.mat >= 0 && d.mat < s->n_materials) ? mats[d.mat].flags : 0;      // k_intersect: does a hit here spawn children?
+            const size_t g = (size_t)s->surf_geom[i];
+            if (d.kind == RT_SURF_SPHERE) for (int k = 0; k < 3; ++k) d.p[k] = s->sph_center[3 * g + k];
+            if (d.kind == RT_SURF_BOX) { for (int k = 0; k < 3; ++k) d.p[k] = s->box_center[3 * g + k]; d.p[3] = s->box_scale[g]; }
+            if (d.kind == RT_SURF_PLANE) for (int k = 0; k < 3; ++k) d.p[k] = s->pln_normal[3 * g + k];
+        }
+    });
+    TRY_C(upload(ctx, ctx->scene_allocs, surfs, &ctx->S.surfs));
     TRY_C(upload(ctx, ctx->scene_allocs, mats, &ctx->S.mats));
     std::vector<DLight> lights(s->n_lights);
     std::vector<int32_t> sl;
@@ -2721,7 +2976,7 @@ static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
     // levels >= 1 may hold up to `growth` rays per slot (two children per hit) and usually hold a fraction of one: their queues and
     // sets start at growth / deep_div = 1 ray per slot; deep_div is halved, then growth doubled, when a level overflows.
     const uint64_t want_full = (uint64_t)((double)slots * ctx->growth) + 1024;
-    if (want_full > 0xFFFFFFF0ull) return fail(ctx, RT_ERR_UNSUPPORTED, "ray queue would exceed 2^32 entries");
+    if (want_full > 0x7FFFFFF0ull) return fail(ctx, RT_ERR_UNSUPPORTED, "ray queue would exceed 2^31 entries");      // (k_intersect parks children as queue index << 1 | kind)
     const double want_qd = (double)want_full * ctx->qgrowth;
     const uint32_t want_q = (uint32_t)(want_qd < 2147483647.0 ? want_qd : 2147483647.0);
     const uint64_t want_deep = std::min<uint64_t>(want_full, (uint64_t)((double)want_full / ctx->deep_div) + 1024);
@@ -2922,7 +3177,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
     // never more than the slots there are, so that neither side ever waits for the other to retire (no kernel here spins on
     // another one's results, but a side that cannot get a slot runs after the other instead of beside it).
     const bool slots_ok = ctx->env.ovl_main >= 1 && ctx->env.ovl_side >= 1 && ctx->env.ovl_main + ctx->env.ovl_side <= 4 &&
-                          ctx->env.ovl_main2 + ctx->env.ovl_side <= 4;
+                          ctx->env.ovl_main2 + ctx->env.ovl_side <= 6;      // (the per-ray kernels after the beam set-up use fewer registers: five of them and one 128-register workgroup fit a CU)
     const bool overlap = fast && !prof && rec >= 1 && fb0 != ctx->fb && ctx->two_sets && !(p->flags & RT_FLAG_NO_OVERLAP) && ctx->n_cu >= 8 && slots_ok;
     const int ovl_main = ctx->env.ovl_main;     // workgroups per CU, level-0 side
     const int ovl_side = ctx->env.ovl_side;     // deeper levels
@@ -2952,7 +3207,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                     // level-0 side is the long one, 5.45 / 5.38 - there they take the CUs).
                     int bw = ctx->env.bin_wgs > 0 ? ctx->env.bin_wgs : ((overlap && side == 1 && ctx->fb_slots_frame <= (4u << 20)) ? ovl_main : 8);
                     const dim3 gt((ctx->n_cu * bw + 7) & ~7);
-                    hipLaunchKernelGGL(k_block_box, gt, block, 0, s_, ctx->S, lp, hb, bb, ctx->ctl);
+                    if (!gen) hipLaunchKernelGGL(k_block_box, gt, block, 0, s_, ctx->S, lp, hb, bb, ctx->ctl);      // (else: k_intersect<.., true> wrote the boxes)
                     hipLaunchKernelGGL(k_bin_zone, gt, block, 0, s_, ctx->S, ctx->F, lp, bb, ctx->ctl);
                     hipLaunchKernelGGL(k_bin_tiles, gt, block, 0, s_, ctx->S, ctx->F, lp, bb, ctx->ctl);
                 }
@@ -2985,18 +3240,25 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         }
         return RT_OK;
     };
-    auto intersect = [&](int level, hipStream_t s_, RayQ &qc, HitBuf &hb, double *fbx, int side_, BeamBuf &bb) {
+    // nearest hits of `level` (queue qc) + its hits' children into qn
+    auto intersect = [&](int level, hipStream_t s_, RayQ &qc, RayQ &qn, HitBuf &hb, double *fbx, int side_, BeamBuf &bb) {
         uint32_t *bc = beam ? bb.queue_n : nullptr;
         set_level(level);
         static const GenParams none{};
         int32_t *ids = level == 0 ? d_ids : nullptr;
+        TileOut to{nullptr, nullptr, 0u};
         if (level == 0 && gen) {
-            // the camera-ray pass also zeroes the other framebuffers of the frame
+            // the camera-ray pass also zeroes the other framebuffers of the frame, and writes the block boxes of the tile beams
             double *side = fbx != ctx->fb ? ctx->fb : nullptr, *side2 = (fbm != ctx->fb && fbm != fbx) ? fbm : nullptr;
-            if (fast) hipLaunchKernelGGL((k_intersect<true, true>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side_)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, *gen, bc, side, side2);
-            else hipLaunchKernelGGL((k_intersect<false, true>), dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, *gen, bc, side, side2);
-        } else if (fast) hipLaunchKernelGGL((k_intersect<true, false>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side_)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, none, bc, nullptr, nullptr);
-        else hipLaunchKernelGGL((k_intersect<false, false>), dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl, fbx, ids, none, bc, nullptr, nullptr);
+            if (lp.tiles) {
+                const TileGrid G(gen->n_slots, lp.tile_stride);
+                to.blockbox = bb.blockbox; to.zcnt = bb.zcnt; to.zrows = G.nzone * (uint32_t)ctx->S.n_shadow_lights;
+            }
+            if (fast) hipLaunchKernelGGL((k_intersect<true, true>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side_)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, qn, hb, ctx->ctl, fbx, ids, *gen, bc, side, side2, to);
+            else hipLaunchKernelGGL((k_intersect<false, true>), dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, qn, hb, ctx->ctl, fbx, ids, *gen, bc, side, side2, to);
+        } else if (fast && ctx->F.inv_seg_len > 0.0f) hipLaunchKernelGGL((k_intersect<true, false, true>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side_)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, qn, hb, ctx->ctl, fbx, ids, none, bc, nullptr, nullptr, to);
+        else if (fast) hipLaunchKernelGGL((k_intersect<true, false>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side_)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, qn, hb, ctx->ctl, fbx, ids, none, bc, nullptr, nullptr, to);
+        else hipLaunchKernelGGL((k_intersect<false, false>), dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, qn, hb, ctx->ctl, fbx, ids, none, bc, nullptr, nullptr, to);
     };
     auto queue_of = [&](int level) -> RayQ & { return level == 0 ? ctx->q[0] : ctx->q[1 + ((level - 1) & 1)]; };
 
@@ -3027,36 +3289,29 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
             BeamBuf &bb = level == 0 ? ctx->beam : ctx->beam1;
             const int e = 2 + 6 * level;
             PROF_MARK(e + 0);
-            intersect(level, st, qc, hb, level == 0 ? fb0 : fbm, 0, bb);
+            intersect(level, st, qc, qn, hb, level == 0 ? fb0 : fbm, 0, bb);
             PROF_MARK(e + 1);
             PROF_MARK(e + 2);
             if (int rc = shadows(level, st, qc, hb, level == 0 ? ctx->seg : ctx->seg1, bb, 0)) return rc;
             PROF_MARK(e + 3);
             PROF_MARK(e + 4);
-            if (level == 0) {
-                if (fb0 != ctx->fb) hipLaunchKernelGGL((k_shade<RT_SHADE_LIGHTS | RT_SHADE_STORE>), dim3(ctx->g_shade), block, 0, st, ctx->S, lp, qc, qn, hb, ctx->ctl, fb0, bb.litbits, bb.pair_slot, bb.queue_n);
-                else hipLaunchKernelGGL(k_shade<RT_SHADE_LIGHTS>, dim3(ctx->g_shade), block, 0, st, ctx->S, lp, qc, qn, hb, ctx->ctl, fb0, bb.litbits, bb.pair_slot, bb.queue_n);
-                hipLaunchKernelGGL(k_shade<RT_SHADE_SPAWN>, dim3(ctx->g_shade), block, 0, st, ctx->S, lp, qc, qn, hb, ctx->ctl, ctx->fb, bb.litbits, bb.pair_slot, bb.queue_n);
-            } else
-                hipLaunchKernelGGL(k_shade<3>, dim3(ctx->g_shade), block, 0, st, ctx->S, lp, qc, qn, hb, ctx->ctl, ctx->fb, bb.litbits, bb.pair_slot, bb.queue_n);
+            if (level == 0 && fb0 != ctx->fb) hipLaunchKernelGGL((k_shade<RT_SHADE_LIGHTS | RT_SHADE_STORE>), dim3(ctx->g_shade), block, 0, st, ctx->S, lp, qc, hb, ctx->ctl, fb0, ctx->fb, bb.litbits, bb.pair_slot, bb.queue_n);
+            else hipLaunchKernelGGL(k_shade<RT_SHADE_LIGHTS>, dim3(ctx->g_shade), block, 0, st, ctx->S, lp, qc, hb, ctx->ctl, level == 0 ? fb0 : ctx->fb, ctx->fb, bb.litbits, bb.pair_slot, bb.queue_n);
             PROF_MARK(e + 5);
         }
     } else {
         hipStream_t s2_ = ctx->stream2;
-        intersect(0, st, ctx->q[0], ctx->hb, fb0, 0, ctx->beam);
+        intersect(0, st, ctx->q[0], ctx->q[1], ctx->hb, fb0, 0, ctx->beam);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
         HIP_TRY(ctx, hipStreamWaitEvent(s2_, ctx->ev_fork, 0));
         // level 0 (caller's stream) is submitted first: the host needs ~10 us per launch, and the long chain of the
         // deeper levels must not delay the submission of the frame's largest kernel
         if (int rc = shadows(0, st, ctx->q[0], ctx->hb, ctx->seg, ctx->beam, 1)) return rc;
-        hipLaunchKernelGGL((k_shade<RT_SHADE_LIGHTS | RT_SHADE_STORE>), dim3(gsz(ctx->g_shade, ctx->nb_shade, 3)), block, 0, st, ctx->S, lp, ctx->q[0], ctx->q[1], ctx->hb, ctx->ctl, fb0,
+        hipLaunchKernelGGL((k_shade<RT_SHADE_LIGHTS | RT_SHADE_STORE>), dim3(gsz(ctx->g_shade, ctx->nb_shade, 3)), block, 0, st, ctx->S, lp, ctx->q[0], ctx->hb, ctx->ctl, fb0, ctx->fb,
                            ctx->beam.litbits, ctx->beam.pair_slot, ctx->beam.queue_n);
         // deeper levels (stream2): few, long rays - their waves ask for issue priority over the level-0 waves
         // (in frames of many million pixels the level-0 side is the long one and the priority only slows it down)
         lp.prio = ctx->env.no_prio ? 0 : (ctx->env.prio || ctx->fb_slots_frame <= (4u << 20) ? 1 : 0);
-        set_level(0);
-        hipLaunchKernelGGL(k_shade<RT_SHADE_SPAWN>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s2_, ctx->S, lp, ctx->q[0], ctx->q[1], ctx->hb, ctx->ctl, ctx->fb,
-                           ctx->beam.litbits, ctx->beam.pair_slot, ctx->beam.queue_n);
         const bool no_pipe = ctx->env.no_pipeline;
         if (ctx->three_sets && rec >= 2 && !no_pipe) {
             // Soft shadows of consecutive levels run side by side (odd levels on stream3, even levels on stream4: each is a latency
@@ -3089,22 +3344,14 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                 RayQ &qc = pq(level), &qn = pq(level + 1);
                 // set and queue of level - nd are reused: its shading must be through
                 if (level > nd) HIP_TRY(ctx, hipStreamWaitEvent(s2_, ctx->ev_lit[level - nd], 0));
-                intersect(level, s2_, qc, hb, fbm, 2, bb);
+                intersect(level, s2_, qc, qn, hb, fbm, 2, bb);       // (+ the children: the next link of the frame's critical chain needs nothing else)
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_hit[level], s2_));
-                // the chain of nearest-hit queries is the critical one: its next link is submitted first
-                if (level < rec)
-                    hipLaunchKernelGGL(k_shade<RT_SHADE_SPAWN>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s2_, ctx->S, lp, qc, qn, hb, ctx->ctl, ctx->fb,
-                                       bb.litbits, bb.pair_slot, bb.queue_n);
                 hipStream_t s3_ = (odd || ctx->env.one_shadow_stream) ? ctx->stream3 : s4_;
                 HIP_TRY(ctx, hipStreamWaitEvent(s3_, ctx->ev_hit[level], 0));
                 if (int rc = shadows(level, s3_, qc, hb, sg, bb, 2)) return rc;
                 if (level >= 2) HIP_TRY(ctx, hipStreamWaitEvent(s3_, ctx->ev_lit[level - 1], 0));
-                if (level < rec)
-                    hipLaunchKernelGGL(k_shade<RT_SHADE_LIGHTS>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s3_, ctx->S, lp, qc, qn, hb, ctx->ctl, ctx->fb,
-                                       bb.litbits, bb.pair_slot, bb.queue_n);
-                else      // last level: no children, the would-be children's background is added with the Phong term
-                    hipLaunchKernelGGL(k_shade<3>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s3_, ctx->S, lp, qc, qn, hb, ctx->ctl, ctx->fb,
-                                       bb.litbits, bb.pair_slot, bb.queue_n);
+                hipLaunchKernelGGL(k_shade<RT_SHADE_LIGHTS>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s3_, ctx->S, lp, qc, hb, ctx->ctl, ctx->fb, ctx->fb,
+                                   bb.litbits, bb.pair_slot, bb.queue_n);
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_lit[level], s3_));
             }
             lp.prio = 0;
@@ -3112,9 +3359,9 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         } else {
             for (int level = 1; level <= rec; ++level) {
                 RayQ &qc = queue_of(level), &qn = queue_of(level + 1);
-                intersect(level, s2_, qc, ctx->hb1, fbm, 2, ctx->beam1);
+                intersect(level, s2_, qc, qn, ctx->hb1, fbm, 2, ctx->beam1);
                 if (int rc = shadows(level, s2_, qc, ctx->hb1, ctx->seg1, ctx->beam1, 2)) return rc;
-                hipLaunchKernelGGL(k_shade<3>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s2_, ctx->S, lp, qc, qn, ctx->hb1, ctx->ctl, ctx->fb,
+                hipLaunchKernelGGL(k_shade<RT_SHADE_LIGHTS>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s2_, ctx->S, lp, qc, ctx->hb1, ctx->ctl, ctx->fb, ctx->fb,
                                    ctx->beam1.litbits, ctx->beam1.pair_slot, ctx->beam1.queue_n);
             }
             lp.prio = 0;
@@ -3245,7 +3492,9 @@ extern "C" int rt_render_device_noalloc(rt_ctx *ctx, const rt_render_params *p, 
     ctx->prof_levels = -1;
     if (rc == RT_OK) rc = enqueue_frame(ctx, &q, g, sh, rec, d_rgb, d_rgb8, d_ids, st, false);
     static_cast<FrameState &>(*ctx) = saved;            // the kernels hold their pointers by value
-    ctx->last_noalloc = true;
+    // (enqueue_frame set frame_pending / last_* only when the whole frame was enqueued; a failed call leaves the context
+    // describing the previous frame, growth policy included)
+    if (rc == RT_OK) ctx->last_noalloc = true;
     return rc;
 }
 

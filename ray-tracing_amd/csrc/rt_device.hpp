@@ -68,6 +68,7 @@ struct DPlane {
 struct DSurf {            // by list position (Q8): what the shading stage reads for hit id k
     double p[4];          // sphere: centre; box: centre + scale; plane: normal
     int32_t kind, mat;
+    int32_t mflags, pad;  // DMat::flags of the surface's material (0 when it has none): does a hit here spawn children?
 };
 struct DMat {
     double kd[3], ks[3], kr[3], T;
@@ -215,6 +216,10 @@ __device__ __forceinline__ d3 jitter3(uint32_t seed, uint32_t pixel, uint32_t pa
     const double k = 1.0 / 65536.0;
     return mk3(-g + (2 * g) * ((double)x * k), -g + (2 * g) * ((double)y * k), -g + (2 * g) * ((double)z * k));
 }
+
+// path code of a child ray (jitter hash key): root 1, through 2k, mirror 2k + 1 - must stay identical to child_path() in
+// oracle/oracle.cpp
+__device__ __forceinline__ uint32_t child_path(uint32_t path, uint32_t mirror) { return path * 2u + mirror; }
 
 // util.get_orthonormal_vector (util.py:113-132) + create_orthonormal_basis (util.py:65-75)
 __device__ __forceinline__ void light_basis(d3 D, d3 &up, d3 &right) {

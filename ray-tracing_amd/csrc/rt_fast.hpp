@@ -51,6 +51,7 @@ struct FastScene {
     // every cut location and root bound of the tree, per axis, rounded to float32, sorted, distinct (on_node_plane)
     const float *cuts[3];
     int32_t n_cuts[3];
+    float inv_seg_len;              // 1 / length of the pieces k_intersect cuts long rays into (0: never cut)
 };
 
 // Could coordinate v (float64 -> float32) on axis ax be EXACTLY a bound of some node?  A ray that starts in such a plane
@@ -68,7 +69,13 @@ __device__ __forceinline__ bool on_node_plane(const FastScene &F, int ax, float 
     return lo < F.n_cuts[ax] && a[lo] == v;
 }
 
+#ifdef RT_TRAV_STATS
+#define RT_TS(x) x
+#else
+#define RT_TS(x)
+#endif
 struct FastState {
+    RT_TS(uint32_t n_node = 0; uint32_t n_leaf = 0; uint32_t n_batch = 0; uint32_t n_conf = 0;)
     Hit best;
     bool tie;
     bool stop;       // shadow early-out taken
@@ -100,44 +107,55 @@ __device__ __forceinline__ void fast_consider(const DScene &S, FastState &st, d3
     }
 }
 
-// o, d: the float64 ray.  tlim: float32 upper bound of the ray parameters that can matter
-// (+inf for ordinary rays).  early_dist: stop as soon as a confirmed hit is closer than this
-// (-inf for ordinary rays).  stk: this lane's LDS stack column (stride RT_STACK_STRIDE entries).
-template <int STRIDE>
-__device__ __forceinline__ void fast_nearest(const DScene &S, const FastScene &F, uint2 *stk, d3 o, d3 d, float tlim,
-                                             double early_dist, FastState &st) {
+// float32 view of a ray, shared by the plane loop, the root interval and the tree walk
+struct FastRay {
+    float of0, of1, of2;        // origin (float part)
+    float ol0, ol1, ol2;        // origin - (double)float part
+    float df0, df1, df2;        // direction
+    float in0, in1, in2;        // reciprocal direction, clamped to +-1e30
+    float E0, E1, E2, Emax;     // absolute slack of a plane distance along each axis
+    float af, dnf, K;           // |d|^2, |d| rounded up, magnitude bound of the coordinates involved
+};
+__device__ __forceinline__ FastRay fast_ray(const FastScene &F, d3 o, d3 d) {
+    FastRay R;
+    R.of0 = (float)o.x; R.of1 = (float)o.y; R.of2 = (float)o.z;
+    R.ol0 = (float)(o.x - (double)R.of0); R.ol1 = (float)(o.y - (double)R.of1); R.ol2 = (float)(o.z - (double)R.of2);
+    R.df0 = (float)d.x; R.df1 = (float)d.y; R.df2 = (float)d.z;
+    // reciprocal clamped to +-1e30: a zero (or float-underflowed) direction component behaves like a ray
+    // parallel to that axis, and every product below stays finite or overflows to a harmless +-inf
+    R.in0 = fminf(fmaxf(1.0f / R.df0, -1e30f), 1e30f);
+    R.in1 = fminf(fmaxf(1.0f / R.df1, -1e30f), 1e30f);
+    R.in2 = fminf(fmaxf(1.0f / R.df2, -1e30f), 1e30f);
+    R.K = fmaxf(fmaxf(fabsf(R.of0), fabsf(R.of1)), fmaxf(fabsf(R.of2), F.extent));
+    const float Eabs = R.K * RT_2M19;
+    R.E0 = Eabs * fabsf(R.in0); R.E1 = Eabs * fabsf(R.in1); R.E2 = Eabs * fabsf(R.in2);
+    R.Emax = fmaxf(R.E0, fmaxf(R.E1, R.E2));
+    R.af = fmaf(R.df0, R.df0, fmaf(R.df1, R.df1, R.df2 * R.df2));             // |d|^2 (float32)
+    R.dnf = sqrtf(R.af) * 1.000001f;                                           // |d| rounded up
+    return R;
+}
+
+// tlim: float32 upper bound of the ray parameters that can matter (+inf for ordinary rays)
+__device__ __forceinline__ void fast_init(FastState &st, float tlim) {
     st.best.p = mk3(dnan(), dnan(), dnan());
     st.best.dist = dinf();
     st.best.id = 0;
     st.tie = false;
     st.stop = false;
     st.tbest = tlim;
+}
 
-    const float of0 = (float)o.x, of1 = (float)o.y, of2 = (float)o.z;
-    const float ol0 = (float)(o.x - (double)of0), ol1 = (float)(o.y - (double)of1), ol2 = (float)(o.z - (double)of2);
-    const float df0 = (float)d.x, df1 = (float)d.y, df2 = (float)d.z;
-    // reciprocal clamped to +-1e30: a zero (or float-underflowed) direction component behaves like a ray
-    // parallel to that axis, and every product below stays finite or overflows to a harmless +-inf
-    const float in0 = fminf(fmaxf(1.0f / df0, -1e30f), 1e30f);
-    const float in1 = fminf(fmaxf(1.0f / df1, -1e30f), 1e30f);
-    const float in2 = fminf(fmaxf(1.0f / df2, -1e30f), 1e30f);
-    const float K = fmaxf(fmaxf(fabsf(of0), fabsf(of1)), fmaxf(fabsf(of2), F.extent));
-    const float Eabs = K * RT_2M19;
-    const float E0 = Eabs * fabsf(in0), E1 = Eabs * fabsf(in1), E2 = Eabs * fabsf(in2);
-    const float Emax = fmaxf(E0, fmaxf(E1, E2));
-    const float af = fmaf(df0, df0, fmaf(df1, df1, df2 * df2));                 // |d|^2 (float32)
-    const float dnf = sqrtf(af) * 1.000001f;                                    // |d| rounded up
-
-    // ---- planes (root list, few, wave-uniform): float32 reject, float64 decision -------------
+// ---- planes (root list, few, wave-uniform): float32 reject, float64 decision -------------
+__device__ __forceinline__ void fast_planes(const DScene &S, const FastRay &R, d3 o, d3 d, double early_dist, FastState &st) {
     for (int k = 0; k < S.n_planes; ++k) {
         const DPlane &pl = S.planes[k];
         const float n0 = (float)pl.n[0], n1 = (float)pl.n[1], n2 = (float)pl.n[2];
-        float vn = fmaf(df0, n0, fmaf(df1, n1, df2 * n2));
-        float evn = RT_2M20 * (fabsf(df0 * n0) + fabsf(df1 * n1) + fabsf(df2 * n2));
+        float vn = fmaf(R.df0, n0, fmaf(R.df1, n1, R.df2 * n2));
+        float evn = RT_2M20 * (fabsf(R.df0 * n0) + fabsf(R.df1 * n1) + fabsf(R.df2 * n2));
         if (vn > evn) continue;                                   // certainly facing away: one-sided planes miss
         if (st.tbest < __int_as_float(0x7f800000) && vn < -evn) { // segment end known: is the plane beyond it?
-            float num = -(fmaf(of0, n0, fmaf(of1, n1, of2 * n2)) + (float)pl.d);
-            float enum_ = RT_2M19 * (fabsf(of0 * n0) + fabsf(of1 * n1) + fabsf(of2 * n2) + fabsf((float)pl.d)) + RT_2M19 * K;
+            float num = -(fmaf(R.of0, n0, fmaf(R.of1, n1, R.of2 * n2)) + (float)pl.d);
+            float enum_ = RT_2M19 * (fabsf(R.of0 * n0) + fabsf(R.of1 * n1) + fabsf(R.of2 * n2) + fabsf((float)pl.d)) + RT_2M19 * R.K;
             // t = num / vn with vn < 0: t > tbest  <=>  num < tbest * vn  (both sides bounded conservatively)
             float rhs = st.tbest * (vn - evn) * 1.000002f;         // more negative than tbest*vn
             if (num + enum_ < rhs) continue;                       // certainly beyond the segment
@@ -146,24 +164,36 @@ __device__ __forceinline__ void fast_nearest(const DScene &S, const FastScene &F
         if (plane_exact(o, d, pl, t)) fast_consider(S, st, o, d, t, pl.id, early_dist);
         if (st.stop) return;
     }
+}
 
-    // ---- root interval (float32, conservative) ------------------------------------------------
-    float tmin, tmax;
-    {
-        float a0 = (F.root_lo[0] - of0) * in0, b0 = (F.root_hi[0] - of0) * in0;
-        float a1 = (F.root_lo[1] - of1) * in1, b1 = (F.root_hi[1] - of1) * in1;
-        float a2 = (F.root_lo[2] - of2) * in2, b2 = (F.root_hi[2] - of2) * in2;
-        float n0 = fminf(a0, b0), x0 = fmaxf(a0, b0);
-        float n1 = fminf(a1, b1), x1 = fmaxf(a1, b1);
-        float n2 = fminf(a2, b2), x2 = fmaxf(a2, b2);
-        n0 -= fmaf(fabsf(n0), RT_2M20, E0); x0 += fmaf(fabsf(x0), RT_2M20, E0);
-        n1 -= fmaf(fabsf(n1), RT_2M20, E1); x1 += fmaf(fabsf(x1), RT_2M20, E1);
-        n2 -= fmaf(fabsf(n2), RT_2M20, E2); x2 += fmaf(fabsf(x2), RT_2M20, E2);
-        tmin = fmaxf(fmaxf(n0, n1), fmaxf(n2, 0.0f));
-        tmax = fminf(fminf(x0, x1), fminf(x2, st.tbest));
-    }
+// ---- root interval (float32, conservative): the part of [0, tcap] inside the tree's root box; false: none -----------
+__device__ __forceinline__ bool fast_root_interval(const FastScene &F, const FastRay &R, float tcap, float &tmin, float &tmax) {
+    float a0 = (F.root_lo[0] - R.of0) * R.in0, b0 = (F.root_hi[0] - R.of0) * R.in0;
+    float a1 = (F.root_lo[1] - R.of1) * R.in1, b1 = (F.root_hi[1] - R.of1) * R.in1;
+    float a2 = (F.root_lo[2] - R.of2) * R.in2, b2 = (F.root_hi[2] - R.of2) * R.in2;
+    float n0 = fminf(a0, b0), x0 = fmaxf(a0, b0);
+    float n1 = fminf(a1, b1), x1 = fmaxf(a1, b1);
+    float n2 = fminf(a2, b2), x2 = fmaxf(a2, b2);
+    n0 -= fmaf(fabsf(n0), RT_2M20, R.E0); x0 += fmaf(fabsf(x0), RT_2M20, R.E0);
+    n1 -= fmaf(fabsf(n1), RT_2M20, R.E1); x1 += fmaf(fabsf(x1), RT_2M20, R.E1);
+    n2 -= fmaf(fabsf(n2), RT_2M20, R.E2); x2 += fmaf(fabsf(x2), RT_2M20, R.E2);
+    tmin = fmaxf(fmaxf(n0, n1), fmaxf(n2, 0.0f));
+    tmax = fminf(fminf(x0, x1), fminf(x2, tcap));
+    return !(tmin > tmax);
+}
+
+// ---- the tree, for the ray parameters [tmin, tmax] (inside the root interval; any sub-range of it: every leaf whose
+// conservative interval meets the range is visited, and every primitive of a visited leaf is tested whole) -----------
+// early_dist: stop as soon as a confirmed hit is closer than this (-inf for ordinary rays).
+// stk: this lane's LDS stack column (stride STRIDE entries).
+template <int STRIDE>
+__device__ __forceinline__ void fast_tree(const DScene &S, const FastScene &F, uint2 *stk, const FastRay &R, d3 o, d3 d, float tmin, float tmax,
+                                          double early_dist, FastState &st) {
+    const float of0 = R.of0, of1 = R.of1, of2 = R.of2, ol0 = R.ol0, ol1 = R.ol1, ol2 = R.ol2;
+    const float df0 = R.df0, df1 = R.df1, df2 = R.df2, in0 = R.in0, in1 = R.in1, in2 = R.in2;
+    const float E0 = R.E0, E1 = R.E1, E2 = R.E2, Emax = R.Emax, af = R.af, dnf = R.dnf;
+    tmax = fminf(tmax, st.tbest);
     if (tmin > tmax) return;
-
     uint32_t node = 0;
     int sp = 0;
     for (;;) {
@@ -171,6 +201,7 @@ __device__ __forceinline__ void fast_nearest(const DScene &S, const FastScene &F
         // ---- descend to a leaf, near child first ----
         while ((nd.b & 3u) != 3u) {
             const uint32_t ax = nd.b & 3u;
+            RT_TS(++st.n_node;)
             const float cut = __uint_as_float(nd.a);
             const float oa = ax == 0 ? of0 : (ax == 1 ? of1 : of2);
             const float ia = ax == 0 ? in0 : (ax == 1 ? in1 : in2);
@@ -197,7 +228,9 @@ __device__ __forceinline__ void fast_nearest(const DScene &S, const FastScene &F
             // ended through the EPSILON rule) costs one to three memory round trips instead of one per entry.  The
             // survivors are confirmed one after the other, in leaf order, by a single copy of the float64 code.
             const uint32_t first = nd.a, last = nd.a + (nd.b >> 2) - 1u;
+            RT_TS(++st.n_leaf;)
             for (uint32_t e0 = first; e0 <= last; e0 += 4u) {
+                RT_TS(++st.n_batch;)
                 LeafF lf4[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) lf4[k] = F.leaves[min(e0 + (uint32_t)k, last)];
@@ -241,6 +274,7 @@ __device__ __forceinline__ void fast_nearest(const DScene &S, const FastScene &F
                 while (mask) {
                     const int k = __builtin_ctz(mask);
                     mask &= mask - 1u;
+                    RT_TS(++st.n_conf;)
                     const uint32_t pk = k == 0 ? lf4[0].pk : (k == 1 ? lf4[1].pk : (k == 2 ? lf4[2].pk : lf4[3].pk));
                     const uint32_t kind = pk & 3u;
                     const DPrim *pr = S.prims + (pk >> 2);
@@ -272,4 +306,19 @@ __device__ __forceinline__ void fast_nearest(const DScene &S, const FastScene &F
             tmax = fminf(__uint_as_float(t2.y), st.tbest);
         }
     }
+}
+
+// o, d: the float64 ray.  tlim: float32 upper bound of the ray parameters that can matter
+// (+inf for ordinary rays).  early_dist: stop as soon as a confirmed hit is closer than this
+// (-inf for ordinary rays).  stk: this lane's LDS stack column (stride STRIDE entries).
+template <int STRIDE>
+__device__ __forceinline__ void fast_nearest(const DScene &S, const FastScene &F, uint2 *stk, d3 o, d3 d, float tlim,
+                                             double early_dist, FastState &st) {
+    fast_init(st, tlim);
+    const FastRay R = fast_ray(F, o, d);
+    fast_planes(S, R, o, d, early_dist, st);
+    if (st.stop) return;
+    float tmin, tmax;
+    if (!fast_root_interval(F, R, st.tbest, tmin, tmax)) return;
+    fast_tree<STRIDE>(S, F, stk, R, o, d, tmin, tmax, early_dist, st);
 }
