@@ -240,7 +240,8 @@ int rt_render_device_noalloc(rt_ctx *ctx, const rt_render_params *p, float *d_rg
 int64_t rt_noalloc_scratch_bytes(void);
 /* Diagnostic: number of allocating HIP calls (hipMalloc, hipHostMalloc, event creation) this library has issued in the process. */
 int64_t rt_debug_alloc_calls(void);
-/* Diagnostic: frames this context has enqueued with tile beams (candidates per 8 x 8 pixel tile by binning, see RT_FLAG_NO_TILES). */
+/* Diagnostic: frames of this context that took the tile beams (candidates per 8 x 8 pixel tile by binning, see RT_FLAG_NO_TILES),
+ * counted when their counters are fetched (rt_sync_stats) and no queue overflow voided them. */
 int64_t rt_debug_tile_frames(const rt_ctx *ctx);
 
 /*

@@ -59,7 +59,8 @@ struct FrameCtl {
     uint32_t n_hits[RT_MAX_LEVELS + 2];
     uint32_t overflow;
     uint32_t overflow_q;                    // ... and it was the float64 shadow-ray queue (bb.queue) that ran out
-    uint32_t overflow_deep, overflow_pad;   // ... and it was the queue of a level >= 1 (sized cap_deep) that ran out
+    uint32_t overflow_deep;                 // ... and it was the queue of a level >= 1 (sized cap_deep) that ran out
+    uint32_t overflow_r;                    // ... and it was the pair records of a buffer set (BeamBuf::rec_cap) that ran out
     unsigned long long reflect_rays, transmit_rays, primary_rays;
     uint32_t n_listed[RT_MAX_LEVELS + 2];   // diagnostics: pairs that needed the per-ray filter / rays that needed
     uint32_t n_queued[RT_MAX_LEVELS + 2];   // the float64 queue, per level (copied by k_shade)
@@ -84,10 +85,6 @@ struct HitBuf {          // per ray slot of the CURRENT queue
     int32_t *id;
     uint32_t *list;      // compacted indices of rays that hit something
     uint32_t *lit;       // [cap * n_shadow_lights] lit-sample counters
-};
-
-struct SegBuf {          // per (hit, shadow light): light-plane basis of Light.get_shadow_rays, computed once
-    double *ux, *uy, *uz, *rx, *ry, *rz, *cx, *cy, *cz;   // up, right, p00 (Light.py:257-260)
 };
 
 struct GenParams {
@@ -352,10 +349,10 @@ __device__ unsigned long long g_trav_time[RT_MAX_LEVELS * 8];     // per level: 
 #endif
 // nearest hit, fast path with exact fallback (ties between different primitives, wild rays, non-kd trees)
 template <bool FAST>
-__device__ __forceinline__ Hit nearest_hit(const DScene &S, const FastScene &F, uint2 *stk, d3 o, d3 d, int stats_level = 0) {
+__device__ __forceinline__ Hit nearest_hit(const DScene &S, const FastScene &F, uint2 *stk, d3 o, d3 d, int stats_level = 0, const uint4 *ltop = nullptr) {
     if (FAST && ray_is_tame(o, d)) {
         FastState st;
-        fast_nearest<RT_BLOCK>(S, F, stk, o, d, __int_as_float(0x7f800000), -dinf(), st);
+        fast_nearest<RT_BLOCK>(S, F, stk, o, d, __int_as_float(0x7f800000), -dinf(), st, ltop);
 #ifdef RT_TRAV_STATS
         {
             unsigned long long *ts = g_trav_stats + 8 * stats_level;
@@ -380,7 +377,7 @@ __device__ __forceinline__ Hit nearest_hit(const DScene &S, const FastScene &F, 
 // FULL = false (the fused camera-ray pass): origin and throughput stay unwritten - nobody traces the ray again, and
 // k_shade knows that a camera ray starts with throughput 1 (LevelParams::unit_thr): 48 of 190 bytes per pixel less.
 template <bool FULL>
-__device__ __forceinline__ bool gen_ray(const GenParams &g, const RayQ &q, uint64_t k, d3 &o, d3 &dn, uint32_t &slot) {
+__device__ __forceinline__ bool gen_ray(const GenParams &g, const RayQ &q, uint64_t k, d3 &o, d3 &dn, uint32_t &slot, bool store = true) {
     uint32_t tile_local = (uint32_t)(k / (uint32_t)(g.tw * g.th));
     uint32_t lane = (uint32_t)(k % (uint32_t)(g.tw * g.th));
     uint32_t tile = g.world > 1 ? (uint32_t)g.rank + tile_local * (uint32_t)g.world : tile_local;
@@ -398,12 +395,14 @@ __device__ __forceinline__ bool gen_ray(const GenParams &g, const RayQ &q, uint6
     dn = dir / norm3(dir);
     o = pos;
     if (FULL) { q.ox[k] = pos.x; q.oy[k] = pos.y; q.oz[k] = pos.z; q.tr[k] = 1.0; q.tg[k] = 1.0; q.tb[k] = 1.0; }
-    q.dx[k] = dn.x; q.dy[k] = dn.y; q.dz[k] = dn.z;
     uint32_t gp = (uint32_t)y * (uint32_t)g.W + (uint32_t)x;
     slot = g.world > 1 ? (uint32_t)k : gp;
-    q.slot[k] = slot;
-    q.gpix[k] = gp;
-    q.path[k] = 1u;
+    if (store) {
+        q.dx[k] = dn.x; q.dy[k] = dn.y; q.dz[k] = dn.z;
+        q.slot[k] = slot;
+        q.gpix[k] = gp;
+        q.path[k] = 1u;
+    }
     return true;
 }
 
@@ -568,6 +567,12 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
     const long long tk0 = wall_clock64();
 #endif
     if (frame_voided_uniform(&ctl->overflow)) return;       // a queue overflowed earlier in this frame: the frame is void
+    // the first levels of the tree, in LDS behind the stacks (rt_fast.hpp)
+    uint4 *ltop = nullptr;
+    if (FAST && F.n_top > 0) {
+        ltop = (uint4 *)(lds_stack + (size_t)(F.depth > 2 ? F.depth : 2) * RT_BLOCK);
+        rt_top_stage(F, ltop);
+    }
     // the level's soft-shadow kernels follow on this stream: their append counters start at zero (saves a memset launch)
     if (beam_counters && blockIdx.x == 0 && threadIdx.x < 3) beam_counters[threadIdx.x] = 0u;
     if (GEN && to.blockbox && blockIdx.x == 0)
@@ -604,10 +609,10 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
             // every output slot is visited exactly once here: the framebuffers are initialised by plain stores
             // (fb: 0 or the background of a miss, below; fb_side: 0) instead of two memsets before the frame
             const bool in_range = active;
-            if (active) active = gen_ray<false>(gp, q, k, o, d, slot);
+            if (active) active = gen_ray<false>(gp, q, k, o, d, slot, !(lp.flags & 0x8000));
             valid_total += active ? 1ull : 0ull;
             const uint32_t zs = active ? slot : ((in_range && gp.world > 1) ? (uint32_t)k : RT_INVALID_SLOT);
-            if (zs != RT_INVALID_SLOT) {
+            if (zs != RT_INVALID_SLOT && !(lp.flags & 0x4000)) {
                 if (!active) { fb[3ull * zs] = 0.0; fb[3ull * zs + 1] = 0.0; fb[3ull * zs + 2] = 0.0; }
                 if (fb_side) { fb_side[3ull * zs] = 0.0; fb_side[3ull * zs + 1] = 0.0; fb_side[3ull * zs + 2] = 0.0; }
                 if (fb_side2) { fb_side2[3ull * zs] = 0.0; fb_side2[3ull * zs + 1] = 0.0; fb_side2[3ull * zs + 2] = 0.0; }
@@ -654,7 +659,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
             // round 0: the lane's own ray, first piece
             if (K > 0u) {
                 const FastRay R = fast_ray(F, o, d);
-                fast_tree<RT_BLOCK>(S, F, stk, R, o, d, rmin, K > 1u ? seg_start(rmin, seg, 1u) : rmax, -dinf(), acc);
+                fast_tree<RT_BLOCK>(S, F, stk, R, o, d, rmin, K > 1u ? seg_start(rmin, seg, 1u) : rmax, -dinf(), acc, ltop);
             }
             if (acc.best.id != 0) { hb.px[k] = acc.best.p.x; hb.py[k] = acc.best.p.y; hb.pz[k] = acc.best.p.z; }
             double best_dist = acc.best.dist;
@@ -702,7 +707,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                 if (have) {
                     const d3 io = mk3(q.ox[s_k], q.oy[s_k], q.oz[s_k]), idv = mk3(q.dx[s_k], q.dy[s_k], q.dz[s_k]);
                     const FastRay R = fast_ray(F, io, idv);
-                    fast_tree<RT_BLOCK>(S, F, stk, R, io, idv, t0, t1, -dinf(), st);
+                    fast_tree<RT_BLOCK>(S, F, stk, R, io, idv, t0, t1, -dinf(), st, ltop);
                 }
                 // merge: the pieces of this lane's ray sit in lanes [a, a + run) of this round
                 const uint32_t excl = incl - n_extra;
@@ -744,7 +749,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                 }
             }
         } else if (active) {
-            const Hit h = nearest_hit<FAST>(S, F, stk, o, d, lp.level);
+            const Hit h = nearest_hit<FAST>(S, F, stk, o, d, lp.level, ltop);
             hid = h.id;
             hp = h.p;
             if (hid != 0) { hb.px[k] = hp.x; hb.py[k] = hp.y; hb.pz[k] = hp.z; }
@@ -878,29 +883,6 @@ __device__ __forceinline__ void exact_basis(const DLight &Lt, int sh_rays, d3 P,
     double gsz = radius / (double)sh_rays;         // Light.py:254
     double c0 = (radius - gsz) / 2;
     p00 = (lpos + c0 * up) - c0 * right;           // Light.py:260
-}
-
-// NO_BEAM / exact modes: the float64 basis once per (hit, shadow light); k_shadow's s*s lanes of a pair reuse it
-__global__ void __launch_bounds__(RT_BLOCK) k_shadow_setup(DScene S, LevelParams lp, HitBuf hb, SegBuf sg, FrameCtl *ctl) {
-    if (ctl->overflow) return;
-    if (lp.prio) __builtin_amdgcn_s_setprio(3);
-    const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
-    const uint32_t nsl = (uint32_t)S.n_shadow_lights;
-    const uint64_t total = (uint64_t)n_hits * nsl;
-    ChunkWalk walk(total);
-    uint64_t first;
-    while (walk.next(first)) {
-        uint64_t seg = first + threadIdx.x;
-        if (seg >= total) continue;
-        uint32_t h = (uint32_t)(seg / nsl), ml = (uint32_t)(seg % nsl);
-        uint32_t r = hb.list[h];
-        d3 P = mk3(hb.px[r], hb.py[r], hb.pz[r]);
-        d3 up, right, p00;
-        exact_basis(S.lights[S.shadow_lights[ml]], lp.sh_rays, P, up, right, p00);
-        sg.ux[seg] = up.x; sg.uy[seg] = up.y; sg.uz[seg] = up.z;
-        sg.rx[seg] = right.x; sg.ry[seg] = right.y; sg.rz[seg] = right.z;
-        sg.cx[seg] = p00.x; sg.cy[seg] = p00.y; sg.cz[seg] = p00.z;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1151,7 +1133,7 @@ template <bool EARLY, bool BOXES, bool TILES>
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) k_beam_setup(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb, BeamBuf bb,
                                                          FrameCtl *ctl) {
     extern __shared__ __align__(16) uint2 lds_stack[];
-    __shared__ uint32_t lbuf_all[(RT_BLOCK / 64) * 128], obuf_all[(RT_BLOCK / 64) * 128];
+    __shared__ unsigned long long obuf_all[(RT_BLOCK / 64) * 128];
     __shared__ uint32_t tl_all[RT_TOUCH * RT_BLOCK];     // [entry][lane]: touched leaf entries of the lane's traversal
     if (ctl->overflow) return;
     if (lp.prio) __builtin_amdgcn_s_setprio(3);
@@ -1159,13 +1141,13 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
     const uint32_t nsl = (uint32_t)S.n_shadow_lights;
     const uint32_t total = n_hits * nsl;           // < 2^32: checked on the host
     const int lane = threadIdx.x & 63;
-    // listed pairs are parked in a wave-private LDS buffer and get their slots 64 at a time (one returning
-    // atomic on the list counter per 64 pairs; see k_shadow_beam)
-    uint32_t *lbuf = lbuf_all + (threadIdx.x >> 6) * 128, *obuf = obuf_all + (threadIdx.x >> 6) * 128;
-    uint32_t ln = 0u, on = 0u;
-    // pair_slot is laid out [shadow light][hit slot]: a wave's 64 hits of one light store / load one 256-byte run
-    auto store_listed = [&](uint32_t slot, uint32_t v) { bb.list[slot] = v; const uint32_t pair = v & ((1u << RT_LIST_NU_SHIFT) - 1u); const uint32_t hh = pair / nsl; bb.pair_slot[(uint64_t)(pair - hh * nsl) * lp.cap + hh] = slot; };
-    auto store_ovf = [&](uint32_t slot, uint32_t pair) { bb.ovlist[slot] = pair; };
+    // overflowing pairs are parked in a wave-private LDS buffer and get their list places 64 at a time (one returning
+    // atomic on the counter per 64 pairs; see k_shadow_beam)
+    unsigned long long *obuf = obuf_all + (threadIdx.x >> 6) * 128;
+    uint32_t on = 0u;
+    auto store_ovf = [&](uint32_t at, unsigned long long v) { bb.ovlist[at] = v; };
+    // record slots: the wave owns the blk_left slots below blk_end (taken bb.rec_blk at a time) and hands them to its pairs in order
+    uint32_t blk_end = 0u, blk_left = 0u;
     // A wave takes 64 CONSECUTIVE HITS and ONE light: neighbouring hits (neighbouring pixels at level 0) send
     // nearly the same beam through the tree, the lanes of a wave stay on one path.
     const uint32_t hit_blocks = (n_hits + 63u) >> 6;
@@ -1179,7 +1161,9 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
         const bool valid = hblk < hit_blocks && h < n_hits;
         const uint32_t seg = h * nsl + ml;
         bool listed = false, ovf = false;
-        uint32_t list_nu = 0u;
+        uint32_t list_nu = 0u, keep = 0u;
+        float4 hdr0 = make_float4(0, 0, 0, 0), hdr1 = hdr0, hdr2 = hdr0, hdr3 = hdr0;
+        d3 Pk = mk3(0, 0, 0);
         if (valid || TILES) {
             const uint32_t r = hb.list[(valid || !TILES) ? h : n_hits - 1u];
             const int m = S.shadow_lights[ml];
@@ -1199,7 +1183,6 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
             const d3 P = mk3(hb.px[r], hb.py[r], hb.pz[r]);
             const DLight &Lt = S.lights[m];
             const d3 dl = ld3(Lt.pos) - P;
-            float4 *rec = bb.rec + (uint64_t)seg * RT_PAIR_UNITS;
             // D = -(light - P)/|light - P|  (Light.py:81: light_direction = -L)
             const float e0 = (float)dl.x, e1 = (float)dl.y, e2 = (float)dl.z;
             // (rsq / rcp: 1 ulp each, like the correctly rounded sqrt + divide they replace; all inside RT_RHO)
@@ -1260,7 +1243,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                     n_atp += c == RT_PLANE_ATP;
                 }
             BeamOut bo;
-            bo.nu = 0; bo.boxmask = 0; bo.overflow = true; bo.occ_all = false; bo.atp_all = false; bo.trips = 0; bo.why = 0;
+            bo.nu = 0; bo.boxmask = 0; bo.keep = 0; bo.overflow = true; bo.occ_all = false; bo.atp_all = false; bo.trips = 0; bo.why = 0;
             if (!delicate || TILES) {
                 if (!TILES && (lp.flags & 0x100)) bo.overflow = false;   // timing experiment only
                 else {
@@ -1276,10 +1259,10 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                         const float lim0 = Rs + RT_2M17 * (fabsf(cB0) + Rs) + 1e-5f, lim1 = Rs + RT_2M17 * (fabsf(cB1) + Rs) + 1e-5f, lim2 = Rs + RT_2M17 * (fabsf(cB2) + Rs) + 1e-5f;
                         if (h0 <= lim0 && h1 <= lim1 && h2 <= lim2) T.row = (r >> 6) * nsl + ml;
                         const bool active = valid && !delicate && !(lp.flags & 0x100);      // (0x100: timing experiment only)
-                        bo = beam_collect<RT_BLOCK, EARLY, BOXES, true>(S, F, bs, tl_all + threadIdx.x, P, cB0, cB1, cB2, h0, h1, h2, Q, rec + 4, lp.flags, active, &T);
+                        bo = beam_collect<RT_BLOCK, EARLY, BOXES, true>(S, F, bs, tl_all + threadIdx.x, P, cB0, cB1, cB2, h0, h1, h2, Q, lp.flags, active, &T);
                         if (delicate) bo.overflow = true;
                     } else
-                    bo = beam_collect<RT_BLOCK, EARLY, BOXES>(S, F, bs, tl_all + threadIdx.x, P, cB0, cB1, cB2, h0, h1, h2, Q, rec + 4, lp.flags);
+                    bo = beam_collect<RT_BLOCK, EARLY, BOXES>(S, F, bs, tl_all + threadIdx.x, P, cB0, cB1, cB2, h0, h1, h2, Q, lp.flags);
                 }
             }
 #ifdef RT_DEBUG_BEAM
@@ -1307,37 +1290,72 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
             if (!range_ok) { bo.overflow = true; delicate = true; }
             if (!valid) {}
             else if (whole) bb.pair_slot[(uint64_t)ml * lp.cap + h] = whole;
-            else if (bo.overflow) {
-                // too many primitives along the beam (or a delicate basis): k_shadow_walk sends each ray through the
-                // tree on its own; it needs the header only.  units = RT_META_OVERFLOW: float64 for every ray.
-                ovf = true;
-                bb.pair_slot[(uint64_t)ml * lp.cap + h] = RT_PAIR_UNLIT;   // nothing from the per-pair filter: the lit count is hb.lit alone
-                const uint32_t meta = (delicate ? RT_META_OVERFLOW : 0u) | ((uint32_t)m << 16) | (pcls << 24);
-                rec[0] = make_float4(q00, q01, q02, g);
-                rec[1] = make_float4(u0, u1, u2, __uint_as_float(meta));
-                rec[2] = make_float4(r0, r1, r2, __uint_as_float(q.gpix[r]));
-                rec[3] = make_float4(pd[0], pd[1], pd[2], __uint_as_float(q.path[r]));
-            } else {
-                listed = true;                              // only now the header is worth its 64 bytes (13 % of the pairs)
-                const uint32_t meta = bo.nu | (bo.boxmask << 4) | ((uint32_t)m << 16) | (pcls << 24) | (bo.atp_all ? 1u << 30 : 0u);
-                list_nu = bo.nu;
-                rec[0] = make_float4(q00, q01, q02, g);
-                rec[1] = make_float4(u0, u1, u2, __uint_as_float(meta));
-                rec[2] = make_float4(r0, r1, r2, __uint_as_float(q.gpix[r]));
-                rec[3] = make_float4(pd[0], pd[1], pd[2], __uint_as_float(q.path[r]));
+            else {
+                // a record: listed pairs (header + candidate units, 13 % of the pairs) and overflowing pairs - too many primitives
+                // along the beam, or a delicate basis: k_shadow_walk sends each ray through the tree on its own and needs the
+                // header only; units = RT_META_OVERFLOW: float64 for every ray
+                ovf = bo.overflow;
+                listed = !ovf;
+                const uint32_t meta = ovf ? ((delicate ? RT_META_OVERFLOW : 0u) | ((uint32_t)m << 16) | (pcls << 24))
+                                          : (bo.nu | (bo.boxmask << 4) | ((uint32_t)m << 16) | (pcls << 24) | (bo.atp_all ? 1u << 30 : 0u));
+                list_nu = ovf ? 0u : bo.nu;
+                keep = ovf ? 0u : bo.keep;
+                Pk = P;
+                hdr0 = make_float4(q00, q01, q02, g);
+                hdr1 = make_float4(u0, u1, u2, __uint_as_float(meta));
+                hdr2 = make_float4(r0, r1, r2, __uint_as_float(q.gpix[r]));
+                hdr3 = make_float4(pd[0], pd[1], pd[2], __uint_as_float(q.path[r]));
             }
         }
-        wave_append(listed, seg | (list_nu << RT_LIST_NU_SHIFT), lbuf, ln, &bb.queue_n[1], lane, store_listed);
-        wave_append(ovf, seg, obuf, on, &bb.queue_n[2], lane, store_ovf);
+        // ---- record slots, in order from the wave's block (one returning atomic per bb.rec_blk records) ----
+        uint32_t slot = RT_LIST_NONE;
+        {
+            const bool need = listed || ovf;
+            const unsigned long long nm = __ballot(need);
+            if (nm) {
+                const uint32_t c = (uint32_t)__popcll(nm), rk = (uint32_t)__popcll(nm & ((1ull << lane) - 1ull));
+                if (c <= blk_left) {
+                    slot = blk_end - blk_left + rk;
+                    blk_left -= c;
+                } else {
+                    const uint32_t more = c - blk_left, take = ((more + bb.rec_blk - 1u) / bb.rec_blk) * bb.rec_blk;
+                    uint32_t nb = 0;
+                    if (lane == 0) nb = atomicAdd(&bb.queue_n[1], take);
+                    nb = __shfl(nb, 0);
+                    slot = rk < blk_left ? blk_end - blk_left + rk : nb + (rk - blk_left);
+                    blk_end = nb + take;
+                    blk_left = take - more;
+                    if (blk_end > bb.rec_cap) {                // out of records: the frame is void, the host renders it again with more
+                        if (lane == 0) ctl->overflow = ctl->overflow_r = 1u;
+                        blk_left = 0u;
+                        if (slot >= nb) slot = RT_LIST_NONE;
+                    }
+                }
+                if (need && slot != RT_LIST_NONE) {
+                    float4 *rec = bb.rec + (uint64_t)slot * RT_PAIR_UNITS;
+                    rec[0] = hdr0; rec[1] = hdr1; rec[2] = hdr2; rec[3] = hdr3;
+                    if (listed) {
+                        beam_write_units<RT_BLOCK, BOXES>(S, tl_all + threadIdx.x, keep, Pk, rec + 4);
+                        bb.list[slot] = seg | (list_nu << RT_LIST_NU_SHIFT);
+                        bb.pair_slot[(uint64_t)ml * lp.cap + h] = slot;    // pair_slot is laid out [shadow light][hit]: a wave's 64 hits of one light store one 256-byte run
+                    } else {
+                        bb.list[slot] = RT_LIST_NONE;
+                        bb.pair_slot[(uint64_t)ml * lp.cap + h] = RT_PAIR_UNLIT;   // nothing from the per-pair filter: the lit count is hb.lit alone
+                    }
+                } else if (need) { ovf = false; listed = false; }
+            }
+        }
+        wave_append(ovf, (unsigned long long)seg | ((unsigned long long)slot << 32), obuf, on, &bb.queue_n[2], lane, store_ovf);
     }
-    wave_append_flush(lbuf, ln, &bb.queue_n[1], lane, store_listed);
+    // the unused tail of the wave's last block: no pair there
+    if ((uint32_t)lane < blk_left) bb.list[blk_end - blk_left + (uint32_t)lane] = RT_LIST_NONE;
     wave_append_flush(obuf, on, &bb.queue_n[2], lane, store_ovf);
 }
 
 // float64-confirmed verdict for shadow ray g (rt_fast.hpp), or the reference-order walk when !FAST
-template <bool FAST, bool STORED>
+template <bool FAST>
 __device__ __forceinline__ bool shadow_ray_lit(const DScene &S, const FastScene &F, uint2 *stk, const LevelParams &lp,
-                                               const RayQ &q, const HitBuf &hb, const SegBuf &sg, uint64_t g) {
+                                               const RayQ &q, const HitBuf &hb, uint64_t g) {
     const uint32_t s = (uint32_t)lp.sh_rays, s2 = s * s;
     const uint32_t nsl = (uint32_t)S.n_shadow_lights;
     const uint64_t seg = g / s2;
@@ -1347,11 +1365,7 @@ __device__ __forceinline__ bool shadow_ray_lit(const DScene &S, const FastScene 
     int m = S.shadow_lights[ml];
     d3 P = mk3(hb.px[r], hb.py[r], hb.pz[r]);
     d3 up, right, p00;
-    if (STORED) {
-        up = mk3(sg.ux[seg], sg.uy[seg], sg.uz[seg]);
-        right = mk3(sg.rx[seg], sg.ry[seg], sg.rz[seg]);
-        p00 = mk3(sg.cx[seg], sg.cy[seg], sg.cz[seg]);
-    } else exact_basis(S.lights[m], lp.sh_rays, P, up, right, p00);
+    exact_basis(S.lights[m], lp.sh_rays, P, up, right, p00);
     double gsz = S.lights[m].radius / (double)(int)s;          // Light.py:254
     d3 src = (p00 - ((double)b * gsz) * up) + ((double)a * gsz) * right;   // Light.py:273-274
     d3 u1 = mk3(0, 0, 0), u2 = mk3(0, 0, 0);
@@ -1398,8 +1412,7 @@ __device__ __forceinline__ void add_lit_counts(uint32_t *lit_ctr, bool active, b
 
 // one lane per soft-shadow ray, every ray decided in float64 (Light.compute_shadows, Light.py:178-288)
 template <bool FAST>
-__global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb, SegBuf sg,
-                                                     FrameCtl *ctl) {
+__global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb, FrameCtl *ctl) {
     extern __shared__ uint2 lds_stack[];
     uint2 *stk = lds_stack + threadIdx.x;
     if (ctl->overflow) return;
@@ -1414,7 +1427,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DScene S, FastScene F, Leve
         uint64_t g = first + threadIdx.x;
         bool active = g < total;
         uint64_t seg = active ? g / s2 : ~0ull;       // (hit, light) pair: h * nsl + ml
-        bool lit = active && shadow_ray_lit<FAST, true>(S, F, stk, lp, q, hb, sg, g);
+        bool lit = active && shadow_ray_lit<FAST>(S, F, stk, lp, q, hb, g);
         add_lit_counts(hb.lit, active, lit, seg, lane);
     }
 }
@@ -1436,7 +1449,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
     const uint32_t NONE = 0xffffffffu;
     const uint32_t s = (uint32_t)lp.sh_rays, s2 = s * s;
     const uint32_t queue_cap = bb.queue_n[3];
-    const uint32_t nlist = min(bb.queue_n[1], min(ctl->n_hits[lp.level], lp.cap) * (uint32_t)S.n_shadow_lights);
+    const uint32_t nlist = min(bb.queue_n[1], bb.rec_cap);      // record slots handed out (RT_LIST_NONE where no listed pair sits)
     const uint32_t nchunks = (nlist + lp.spb - 1) / lp.spb;
     ChunkWalk walk((uint64_t)nchunks * RT_BLOCK);
     uint64_t first;
@@ -1477,17 +1490,17 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
 #define RT_LOAD_PAIRNO(dst_, chunk_) do { const uint32_t sl_ = (chunk_) * lp.spb + wp0 + (uint32_t)lane; \
         dst_ = ((uint32_t)lane < npw && sl_ < nlist) ? bb.list[sl_] : NONE; } while (0)
     // a list entry = pair | units used << 28: only the header and the used candidate units of a record are fetched
-#define RT_LOAD_RECS(pairno_) do { const uint32_t g0_ = __shfl((pairno_), (int)sp0), g1_ = __shfl((pairno_), (int)sp1), g2_ = __shfl((pairno_), (int)sp2); \
-        const uint32_t pm_ = (1u << RT_LIST_NU_SHIFT) - 1u; \
-        if (has0 && g0_ != NONE && su0 < 4u + (g0_ >> RT_LIST_NU_SHIFT)) st0 = bb.rec[(uint64_t)(g0_ & pm_) * RT_PAIR_UNITS + su0]; \
-        if (has1 && g1_ != NONE && su1 < 4u + (g1_ >> RT_LIST_NU_SHIFT)) st1 = bb.rec[(uint64_t)(g1_ & pm_) * RT_PAIR_UNITS + su1]; \
-        if (has2 && g2_ != NONE && su2 < 4u + (g2_ >> RT_LIST_NU_SHIFT)) st2 = bb.rec[(uint64_t)(g2_ & pm_) * RT_PAIR_UNITS + su2]; } while (0)
+#define RT_LOAD_RECS(pairno_, chunk_) do { const uint32_t g0_ = __shfl((pairno_), (int)sp0), g1_ = __shfl((pairno_), (int)sp1), g2_ = __shfl((pairno_), (int)sp2); \
+        const uint64_t b_ = (uint64_t)(chunk_) * lp.spb + wp0;      /* the record of a listed pair sits at its list slot */ \
+        if (has0 && g0_ != NONE && su0 < 4u + (g0_ >> RT_LIST_NU_SHIFT)) st0 = bb.rec[(b_ + sp0) * RT_PAIR_UNITS + su0]; \
+        if (has1 && g1_ != NONE && su1 < 4u + (g1_ >> RT_LIST_NU_SHIFT)) st1 = bb.rec[(b_ + sp1) * RT_PAIR_UNITS + su1]; \
+        if (has2 && g2_ != NONE && su2 < 4u + (g2_ >> RT_LIST_NU_SHIFT)) st2 = bb.rec[(b_ + sp2) * RT_PAIR_UNITS + su2]; } while (0)
     uint32_t cur = 0u, nxt = 0u, pno_cur = NONE, pno_nxt = NONE;
     bool have = walk.next(first), have_n = false;
     if (have) {
         cur = (uint32_t)(first / RT_BLOCK);
         RT_LOAD_PAIRNO(pno_cur, cur);
-        RT_LOAD_RECS(pno_cur);
+        RT_LOAD_RECS(pno_cur, cur);
         have_n = walk.next(first);
         if (have_n) {
             nxt = (uint32_t)(first / RT_BLOCK);
@@ -1506,7 +1519,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
         uint32_t n2 = 0u, pno_n2 = NONE;
         bool have_n2 = false;
         if (have_n) {                                // in flight during the arithmetic below
-            RT_LOAD_RECS(pno_nxt);
+            RT_LOAD_RECS(pno_nxt, nxt);
             have_n2 = walk.next(first);
             if (have_n2) {
                 n2 = (uint32_t)(first / RT_BLOCK);
@@ -1663,8 +1676,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_walk(DScene S, FastScene F,
         if (active) {
             const uint32_t pi = (uint32_t)(i / s2);
             kk = (uint32_t)(i - (uint64_t)pi * s2);
-            seg = bb.ovlist[pi];
-            const float4 *rec = bb.rec + (uint64_t)seg * RT_PAIR_UNITS;
+            const unsigned long long ov = bb.ovlist[pi];
+            seg = (uint32_t)ov;
+            const float4 *rec = bb.rec + (ov >> 32) * RT_PAIR_UNITS;
             const float4 h0 = rec[0], h1 = rec[1], h2 = rec[2], h3 = rec[3];
             const float g = h0.w;
             const uint32_t meta = __float_as_uint(h1.w);
@@ -1723,8 +1737,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_walk(DScene S, FastScene F,
 }
 
 // the rays the filter could not decide, in float64
-__global__ void __launch_bounds__(RT_BLOCK) k_shadow_queue(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb, SegBuf sg,
-                                                           BeamBuf bb, FrameCtl *ctl) {
+__global__ void __launch_bounds__(RT_BLOCK) k_shadow_queue(DScene S, FastScene F, LevelParams lp, RayQ q, HitBuf hb, BeamBuf bb, FrameCtl *ctl) {
     extern __shared__ uint2 lds_stack[];
     uint2 *stk = lds_stack + threadIdx.x;
     if (ctl->overflow) return;
@@ -1748,9 +1761,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_queue(DScene S, FastScene F
         else {
             const uint64_t j = i - n;
             const uint32_t pi = (uint32_t)(j / s2);
-            g = (uint64_t)bb.ovlist[pi] * s2 + (j - (uint64_t)pi * s2);
+            g = (uint64_t)(uint32_t)bb.ovlist[pi] * s2 + (j - (uint64_t)pi * s2);
         }
-        if (shadow_ray_lit<true, false>(S, F, stk, lp, q, hb, sg, g)) atomicAdd(&hb.lit[g / s2], 1u);
+        if (shadow_ray_lit<true>(S, F, stk, lp, q, hb, g)) atomicAdd(&hb.lit[g / s2], 1u);
     }
 }
 
@@ -2200,9 +2213,10 @@ struct FrameState {
     uint32_t beam_queue_cap = 0;
     uint32_t tile_nblk = 0, tile_nreg = 0, tile_nzone = 0;      // what the binning buffers of the tile beams were carved for
     double qgrowth_carved = 1.0;    // float64 shadow-ray queue of a set = its capacity * this
+    double rec_div_carved = 1.0;    // pair records of a set = its (hit, light) pairs / this (+ the waves' block slack)
+    uint32_t spb_carved = 1;        // lit masks for chunks of at least this many pairs (RT_BLOCK / (s * s))
     RayQ q[6]{};            // level 0 -> q[0]; level k >= 1 -> q[1 + (k - 1) % 2] (% 3 / % 5 when the deeper levels are pipelined over 2 / 4 sets)
     HitBuf hb{}, hb1{}, hb2{}, hb3{}, hb4{};   // level 0 / deeper levels, rotating (so are seg*, beam*)
-    SegBuf seg{}, seg1{}, seg2{}, seg3{}, seg4{};
     BeamBuf beam{}, beam1{}, beam2{}, beam3{}, beam4{};
     bool five_sets = false;                 // hb3, hb4 / .. are separate allocations: a level's buffers are reused four levels later
     double *fb = nullptr, *fb0 = nullptr, *fbm = nullptr;   // see k_resolve
@@ -2212,7 +2226,6 @@ struct FrameState {
 };
 
 static HitBuf *hit_set(FrameState &fs, int set) { HitBuf *a[5] = {&fs.hb, &fs.hb1, &fs.hb2, &fs.hb3, &fs.hb4}; return a[set]; }
-static SegBuf *seg_set(FrameState &fs, int set) { SegBuf *a[5] = {&fs.seg, &fs.seg1, &fs.seg2, &fs.seg3, &fs.seg4}; return a[set]; }
 static BeamBuf *beam_set(FrameState &fs, int set) { BeamBuf *a[5] = {&fs.beam, &fs.beam1, &fs.beam2, &fs.beam3, &fs.beam4}; return a[set]; }
 
 // RT_AMD_* environment switches (diagnostics / experiments), read ONCE in rt_create: a frame takes ~2 ms, a getenv per
@@ -2254,7 +2267,8 @@ struct EnvCfg {
 struct rt_ctx : FrameState {
     int device = 0;
     EnvCfg env;
-    int64_t tile_frames = 0;                // frames enqueued with tile beams (rt_debug_tile_frames)
+    int64_t tile_frames = 0;                // frames rendered with tile beams whose counters were fetched and that no queue overflow voided (rt_debug_tile_frames)
+    bool last_tiles = false;                // the last frame enqueued took the tile beams
     unsigned char *stage = nullptr;         // grow-only device staging for the blocking host-buffer entry points (no hipMalloc per call)
     size_t stage_bytes = 0;
     uint32_t *d_voided = nullptr;           // frames voided by a queue overflow since the last rt_voided_frames(reset) (device counter)
@@ -2266,6 +2280,7 @@ struct rt_ctx : FrameState {
     DScene S{};
     FastScene F{};
     size_t lds_bytes = 0;   // per-lane traversal stacks: F.depth * RT_BLOCK * 8
+    size_t lds_top_bytes = 0;   // + the table of the tree's first levels, for the kernels that stage it (rt_top_stage)
     SmallLayout small{};    // scene tables staged in LDS by k_small_level (rt_small.hpp); small_ok: they fit
     bool small_ok = false;
     int g_small = 2048;
@@ -2274,6 +2289,7 @@ struct rt_ctx : FrameState {
     double growth = 2.0;    // queue capacity = growth * primary slots
     double deep_div = 2.0;  // cap_deep = cap / deep_div: a level >= 1 rarely holds more rays than there are camera rays (halved when one does)
     double qgrowth = 1.0;   // float64 shadow-ray queue = qgrowth * queue capacity (grows by itself: large s, many undecided rays)
+    double rec_div = 5.0;   // pair records for 1 / rec_div of a buffer set's (hit, light) pairs (halved when a level runs out: RT_ERR_QUEUE_OVERFLOW)
     std::vector<void *> frame_allocs;
     uint64_t frame_bytes = 0;               // device bytes of the frame state (ensure_frame)
     int env_sets = 0;                       // RT_AMD_SETS / RT_AMD_ONE_SET, read once in rt_create (0 = no limit)
@@ -2648,6 +2664,37 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
             ctx->F.n_cuts[k] = (int32_t)cuts.size();
             TRY_C(upload(ctx, ctx->scene_allocs, cuts, &ctx->F.cuts[k]));
         }
+        {
+            // first levels, breadth first (rt_fast.hpp: FastScene::top)
+            int levels = 8;
+            if (const char *e = getenv("RT_AMD_TOP_LEVELS")) levels = atoi(e);
+            std::vector<uint4> top;
+            if (ok && levels > 0 && s->node_right[0] >= 0) {
+                std::vector<int> order, lvl, pos(nn, -1);      // internal nodes of depth < levels, breadth first
+                order.push_back(0); lvl.push_back(0); pos[0] = 0;
+                for (size_t h = 0; h < order.size(); ++h) {
+                    const int i = order[h];
+                    const int ch[2] = {i + 1, s->node_right[i]};
+                    for (int c = 0; c < 2; ++c)
+                        if (s->node_right[ch[c]] >= 0 && lvl[h] + 1 < levels && (int)order.size() < RT_TOP_MAX_NODES) {
+                            pos[ch[c]] = (int)order.size();
+                            order.push_back(ch[c]); lvl.push_back(lvl[h] + 1);
+                        }
+                }
+                top.resize(order.size());
+                for (size_t h = 0; h < order.size(); ++h) {
+                    const int i = order[h], L = i + 1, R = s->node_right[i];
+                    uint4 t;
+                    t.x = kn[i].a; t.y = kn[i].b & 3u;
+                    t.z = pos[L] >= 0 ? (RT_TOP_FLAG | (uint32_t)pos[L]) : (uint32_t)L;
+                    t.w = pos[R] >= 0 ? (RT_TOP_FLAG | (uint32_t)pos[R]) : (uint32_t)R;
+                    top[h] = t;
+                }
+            }
+            ctx->F.n_top = (int32_t)top.size();
+            TRY_C(upload(ctx, ctx->scene_allocs, top, &ctx->F.top));
+            ctx->lds_top_bytes = top.empty() ? 0 : (size_t)RT_TOP_MAX_NODES * sizeof(uint4);
+        }
         TRY_C(upload(ctx, ctx->scene_allocs, kn, &ctx->F.knodes));
         TRY_C(upload(ctx, ctx->scene_allocs, lf, &ctx->F.leaves));
         TRY_C(upload(ctx, ctx->scene_allocs, prim_entry, &ctx->F.prim_entry));
@@ -2712,7 +2759,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
             return (g + 7) & ~7;
         };
         const size_t lds = ctx->lds_bytes;
-        ctx->g_intersect = grid_for((const void *)&k_intersect<true, false>, lds); ctx->nb_intersect = last_nb;
+        ctx->g_intersect = grid_for((const void *)&k_intersect<true, true>, lds + ctx->lds_top_bytes); ctx->nb_intersect = last_nb;
         ctx->g_intersect_x = grid_for((const void *)&k_intersect<false, false>, 0);
         ctx->g_shadow = grid_for((const void *)&k_shadow<true>, lds); ctx->nb_shadow = last_nb;
         ctx->g_shadow_x = grid_for((const void *)&k_shadow<false>, 0);
@@ -2722,7 +2769,6 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
         ctx->g_queue = grid_for((const void *)&k_shadow_queue, lds); ctx->nb_queue = last_nb;
         ctx->g_walk = grid_for((const void *)&k_shadow_walk, lds); ctx->nb_walk = last_nb;
         ctx->g_shade = grid_for((const void *)&k_shade<RT_SHADE_LIGHTS>, 0); ctx->nb_shade = last_nb;
-        ctx->g_setup = grid_for((const void *)&k_shadow_setup, 0); ctx->nb_setup = last_nb;
         if (getenv("RT_AMD_DEBUG"))
             fprintf(stderr, "[rt_amd] grids: intersect %d beam_setup %d beam %d queue %d shade %d\n", ctx->g_intersect,
                     ctx->g_beam_setup, ctx->g_beam, ctx->g_queue, ctx->g_shade);
@@ -2888,10 +2934,27 @@ static bool tile_scene_ok(const rt_ctx *ctx) {
     return ctx->F.ok && !long_beams && ctx->S.n_prims >= ctx->env.tiles_min_prims && ctx->S.n_prims <= (int)RT_ZONE_NC;
 }
 
+// Record slots a wave of k_beam_setup takes at a time (BeamBuf::rec_blk): one returning atomic per block - 64 where a level
+// holds millions of pairs (one atomic per wave and chunk on one address was a bottleneck there), fewer in small frames, where
+// the unused tail of every wave's last block is what counts.
+static uint32_t rec_block_size(uint64_t pairs) { return pairs >= (1ull << 20) ? 64u : (pairs >= (1ull << 17) ? 32u : 8u); }
+// Record slots of a buffer set of `pairs` (hit, light) pairs: pairs / rec_div, plus the blocks' tails (a wave that takes part
+// handles at least one run of 64 pairs and leaves less than a block unused), a multiple of 64.
+static uint32_t rec_capacity(const rt_ctx *ctx, uint64_t pairs, double rec_div) {
+    const uint64_t waves = (uint64_t)(RT_BLOCK / 64) * (uint64_t)(ctx->n_cu * 6 + 8);        // the largest grid a kernel is launched with
+    const uint64_t slack = (uint64_t)rec_block_size(pairs) * std::min<uint64_t>(waves, pairs / 64 + 1);
+    // (up to a million pairs - 256 MB of records - every pair may have one: the fraction is for the frames whose memory counts)
+    const double div = pairs <= (1ull << 20) ? 1.0 : (rec_div >= 1.0 ? rec_div : 1.0);
+    const uint64_t want = std::max<uint64_t>((uint64_t)((double)pairs / div), std::min<uint64_t>(pairs, 1ull << 20)) + slack + 64;
+    return (uint32_t)std::min<uint64_t>((want + 63) & ~63ull, 0xFFFFFFC0ull);
+}
+
 // Carve the state of a frame of `slots` primary slots with queue capacity `cap` into fs.  sets = 1..3 buffer sets (level 0 /
 // deeper levels odd / even); queues = 3 (levels in sequence) or 4 (pipelined deeper levels).  Nothing is initialised here.
-static int carve_frame(rt_ctx *ctx, Carver &mem, FrameState &fs, uint64_t slots, uint64_t cap0, uint64_t cap_deep, double qgrowth, int sets, int queues, bool tiles,
-                       uint64_t qbase0 = 0) {
+// spb: the fewest pairs a chunk of RT_BLOCK shadow rays will hold in frames on this state (RT_BLOCK / (s * s); 1 = any s): the lit
+// masks of k_shadow_beam are one word per wave and chunk of listed pairs.
+static int carve_frame(rt_ctx *ctx, Carver &mem, FrameState &fs, uint64_t slots, uint64_t cap0, uint64_t cap_deep, double qgrowth, double rec_div, uint32_t spb, int sets,
+                       int queues, bool tiles, uint64_t qbase0 = 0) {
 #define TRY_A(expr) do { int rc_ = (expr); if (rc_ != RT_OK) return rc_; } while (0)
     if (sets < 2) cap_deep = cap0;          // one set: every level lives in it
     auto qcap = [&](uint64_t c) { const double v = (double)c * qgrowth; return (uint32_t)(v < 2147483647.0 ? v : 2147483647.0); };
@@ -2914,15 +2977,14 @@ static int carve_frame(rt_ctx *ctx, Carver &mem, FrameState &fs, uint64_t slots,
         TRY_A(mem.get(&hb.px, cap)); TRY_A(mem.get(&hb.py, cap)); TRY_A(mem.get(&hb.pz, cap));
         TRY_A(mem.get(&hb.id, cap)); TRY_A(mem.get(&hb.list, cap));
         TRY_A(mem.get(&hb.lit, nlit));
-        SegBuf &sg = *seg_set(fs, set);
-        TRY_A(mem.get(&sg.ux, nlit)); TRY_A(mem.get(&sg.uy, nlit)); TRY_A(mem.get(&sg.uz, nlit));
-        TRY_A(mem.get(&sg.rx, nlit)); TRY_A(mem.get(&sg.ry, nlit)); TRY_A(mem.get(&sg.rz, nlit));
-        TRY_A(mem.get(&sg.cx, nlit)); TRY_A(mem.get(&sg.cy, nlit)); TRY_A(mem.get(&sg.cz, nlit));
         BeamBuf &bb = *beam_set(fs, set);
-        TRY_A(mem.get(&bb.rec, (nlit + RT_BLOCK) * RT_PAIR_UNITS));   // + one chunk of slack: staging reads whole chunks
+        const uint64_t rcap = rec_capacity(ctx, nlit, rec_div);
+        bb.rec_cap = (uint32_t)rcap;
+        bb.rec_blk = rec_block_size(nlit);
+        TRY_A(mem.get(&bb.rec, rcap * RT_PAIR_UNITS));
         TRY_A(mem.get(&bb.queue, (uint64_t)queue_cap)); TRY_A(mem.get(&bb.queue_n, 4));
-        TRY_A(mem.get(&bb.litbits, (nlit + 1) * (RT_BLOCK / 64)));      // worst case one pair per chunk (s*s > RT_BLOCK / 2)
-        TRY_A(mem.get(&bb.list, nlit)); TRY_A(mem.get(&bb.pair_slot, nlit)); TRY_A(mem.get(&bb.ovlist, nlit));
+        TRY_A(mem.get(&bb.litbits, (rcap / (spb ? spb : 1u) + 2) * (RT_BLOCK / 64)));
+        TRY_A(mem.get(&bb.list, rcap)); TRY_A(mem.get(&bb.pair_slot, nlit)); TRY_A(mem.get(&bb.ovlist, rcap));
         bb.blockbox = nullptr; bb.trec = nullptr; bb.tcnt = nullptr; bb.zlist = bb.zcnt = nullptr;
         if (set == 0) { fs.tile_nblk = fs.tile_nreg = fs.tile_nzone = 0; }
         if (set == 0 && tiles && tile_scene_ok(ctx)) {
@@ -2936,9 +2998,9 @@ static int carve_frame(rt_ctx *ctx, Carver &mem, FrameState &fs, uint64_t slots,
             fs.tile_nblk = (uint32_t)nblk; fs.tile_nreg = (uint32_t)nreg; fs.tile_nzone = (uint32_t)nzone;
         }
     }
-    if (sets < 2) { fs.hb1 = fs.hb; fs.seg1 = fs.seg; fs.beam1 = fs.beam; }
-    if (sets < 3) { fs.hb2 = fs.hb1; fs.seg2 = fs.seg1; fs.beam2 = fs.beam1; }
-    if (sets < 5) { fs.hb3 = fs.hb1; fs.seg3 = fs.seg1; fs.beam3 = fs.beam1; fs.hb4 = fs.hb2; fs.seg4 = fs.seg2; fs.beam4 = fs.beam2; }
+    if (sets < 2) { fs.hb1 = fs.hb; fs.beam1 = fs.beam; }
+    if (sets < 3) { fs.hb2 = fs.hb1; fs.beam2 = fs.beam1; }
+    if (sets < 5) { fs.hb3 = fs.hb1; fs.beam3 = fs.beam1; fs.hb4 = fs.hb2; fs.beam4 = fs.beam2; }
     fs.two_sets = sets >= 2;
     fs.three_sets = sets >= 3;
     fs.five_sets = sets >= 5;
@@ -2949,6 +3011,8 @@ static int carve_frame(rt_ctx *ctx, Carver &mem, FrameState &fs, uint64_t slots,
     fs.cap = cap0;
     fs.cap_deep = cap_deep;
     fs.qgrowth_carved = qgrowth;
+    fs.rec_div_carved = rec_div;
+    fs.spb_carved = spb ? spb : 1u;
     fs.fb_slots = slots;
     return RT_OK;
 }
@@ -2971,7 +3035,9 @@ static int init_frame_counters(rt_ctx *ctx, FrameState &fs, hipStream_t st) {
 }
 
 // (re)allocate queues for `slots` primary slots; only grows
-static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
+// sh: shadow rays per light and axis of the frame to come (0: none will be cast)
+static int ensure_frame(rt_ctx *ctx, uint64_t slots, int32_t sh) {
+    const uint32_t s2n = (uint32_t)(sh > 0 ? sh * sh : 0), spb = (s2n >= 9u && s2n <= RT_BLOCK) ? RT_BLOCK / s2n : RT_BLOCK;      // (the beam path takes 9 <= s * s <= RT_BLOCK)
     // Level 0 holds the camera rays (or the caller's rays) and nothing else: its queue and buffer set are sized by the slots.  The
     // levels >= 1 may hold up to `growth` rays per slot (two children per hit) and usually hold a fraction of one: their queues and
     // sets start at growth / deep_div = 1 ray per slot; deep_div is halved, then growth doubled, when a level overflows.
@@ -2982,7 +3048,7 @@ static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
     const uint64_t want_deep = std::min<uint64_t>(want_full, (uint64_t)((double)want_full / ctx->deep_div) + 1024);
     uint64_t want_cap = slots + 1024;
     if (ctx->frame_bytes && !ctx->two_sets) want_cap = std::max(want_cap, want_deep);      // one buffer set: every level lives in it
-    if (ctx->cap >= want_cap && ctx->cap_deep >= want_deep && ctx->fb_slots >= slots && ctx->beam_queue_cap >= want_q) {
+    if (ctx->cap >= want_cap && ctx->cap_deep >= want_deep && ctx->fb_slots >= slots && ctx->beam_queue_cap >= want_q && ctx->rec_div_carved <= ctx->rec_div && ctx->spb_carved <= spb) {
         if (ctx->counters_dirty) {
             // the last frame was voided by a queue overflow: its shading kernels returned early and left lit counts behind
             // (k_shade clears them only as it consumes them); a smaller frame that fits the old buffers must not see them
@@ -2995,38 +3061,61 @@ static int ensure_frame(rt_ctx *ctx, uint64_t slots) {
     }
     ctx->counters_dirty = false;
     HIP_TRY(ctx, hipDeviceSynchronize());   // rare: buffers of an in-flight frame are about to be replaced
+    const uint32_t spb_keep = ctx->cap ? std::min(spb, ctx->spb_carved) : spb;      // (frames of fewer pairs per chunk were rendered on the old state: keep serving them)
     free_frame(ctx);
-    uint64_t cap = slots + 1024;
+    const uint64_t cap_l0 = slots + 1024;
     const uint64_t nsl1 = (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1);
-    // Buffer sets two to five are speed-ups only (levels overlap; a level's buffers are reused two / four levels later): without
-    // the memory for them levels share sets and run in sequence.
+    // Buffer sets two to five are speed-ups only (levels overlap; a level's buffers are reused two / four levels later), and so
+    // are the tile beams: without the memory for them levels share sets and run in sequence, pairs walk the tree themselves.
+    // The estimate decides what is tried first; an allocation that fails all the same is tried again with less.
     int sets = 5;
+    bool tiles = !ctx->env.no_tiles;
+    auto set_bytes = [&](uint64_t c) {
+        const uint64_t pairs = c * nsl1, rcap = rec_capacity(ctx, pairs, ctx->rec_div);
+        return c * 40 + pairs * 8 + rcap * (16 * RT_PAIR_UNITS + 12) + (rcap / spb_keep + 2) * 8 * (RT_BLOCK / 64) + (uint64_t)((double)c * ctx->qgrowth) * 8;
+    };
+    auto tile_bytes = [&]() -> uint64_t {
+        if (!tiles || !tile_scene_ok(ctx)) return 0;
+        const uint64_t nblk = (slots + 63) / 64, nreg = nblk / 8 + 64, nzone = nreg / 16 + 8;
+        const uint64_t zcap = std::min<uint64_t>((uint64_t)ctx->S.n_prims, RT_ZONE_NC);
+        return nblk * 32 + nblk * nsl1 * (32 * RT_TILE_NC + 4) + nzone * nsl1 * (zcap + 1) * 4;
+    };
     {
         size_t free_b = 0, total_b = 0;
-        auto set_bytes = [&](uint64_t c) { return c * 40 + c * nsl1 * (4 + 72 + 16 * RT_PAIR_UNITS + 8 * (RT_BLOCK / 64) + 12) + (uint64_t)((double)c * ctx->qgrowth) * 8; };
-        const uint64_t queues_b = (cap + 5 * want_deep) * 84 + (uint64_t)want_qd * 8, fb_b = slots * 72;
-        const uint64_t set0_b = set_bytes(cap), setd_b = set_bytes(want_deep);
+        const uint64_t queues_b = (cap_l0 + 5 * want_deep) * 84 + (uint64_t)want_qd * 8, fb_b = slots * 72;
+        const uint64_t set0_b = set_bytes(cap_l0), setd_b = set_bytes(want_deep);
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) sets = 1;
         else {
             const uint64_t avail = (uint64_t)free_b > queues_b + fb_b ? (uint64_t)free_b - queues_b - fb_b : 0;
-            auto need = [&](int n) { const uint64_t b = set0_b + (uint64_t)(n - 1) * setd_b; return b + b / 8; };
+            auto need = [&](int n) { const uint64_t b = set0_b + (uint64_t)(n - 1) * setd_b + tile_bytes(); return b + b / 16; };
             while (sets > 1 && avail < need(sets)) --sets;
-            if (sets == 4) sets = 3;
+            if (sets == 1 && avail < need(1)) tiles = false;
         }
         if (ctx->env_sets > 0 && ctx->env_sets < sets) sets = ctx->env_sets;      // RT_AMD_SETS = 1, 2, 3 or 5 / RT_AMD_ONE_SET (diagnostic)
         if (sets == 4) sets = 3;
     }
-    if (sets < 2) cap = std::max(cap, want_deep);        // one buffer set: every level lives in it
-    Carver mem{ctx};
-    FrameState fs;
-    fs.ctl = ctx->ctl_own;
-    int rc = carve_frame(ctx, mem, fs, slots, cap, want_deep, ctx->qgrowth, sets, sets >= 5 ? 6 : 4, !ctx->env.no_tiles, want_full);
-    if (rc == RT_OK) rc = init_frame_counters(ctx, fs, ctx->stream);
-    if (rc == RT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, RT_ERR_HIP, "hipStreamSynchronize failed after frame set-up");
-    if (rc != RT_OK) { free_frame(ctx); return rc; }
-    static_cast<FrameState &>(*ctx) = fs;
-    ctx->frame_bytes = mem.used;
-    return RT_OK;
+    int rc = RT_OK;
+    for (;;) {
+        const uint64_t cap = sets < 2 ? std::max(cap_l0, want_deep) : cap_l0;        // one buffer set: every level lives in it
+        Carver mem{ctx};
+        FrameState fs;
+        fs.ctl = ctx->ctl_own;
+        rc = carve_frame(ctx, mem, fs, slots, cap, want_deep, ctx->qgrowth, ctx->rec_div, spb_keep, sets, sets >= 5 ? 6 : 4, tiles, want_full);
+        if (rc == RT_OK) rc = init_frame_counters(ctx, fs, ctx->stream);
+        if (rc == RT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, RT_ERR_HIP, "hipStreamSynchronize failed after frame set-up");
+        if (rc == RT_OK) {
+            static_cast<FrameState &>(*ctx) = fs;
+            ctx->frame_bytes = mem.used;
+            return RT_OK;
+        }
+        free_frame(ctx);
+        (void)hipGetLastError();
+        if (rc != RT_ERR_OOM) return rc;
+        // out of memory although the estimate fitted (other contexts, a PyTorch pool): fewer sets, then no tile beams
+        if (sets > 1) sets = sets == 5 ? 3 : sets - 1;
+        else if (tiles && tile_scene_ok(ctx)) tiles = false;
+        else return rc;
+    }
 }
 
 struct TileGeom {
@@ -3133,6 +3222,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                           double *fb0, const GenParams *gen, double *fbm, const GenParams *cam) {
     LevelParams lp{};
     bool tiles = false;
+    ctx->last_tiles = false;
     lp.sh_rays = sh; lp.jitter = p->jitter; lp.seed = p->seed; lp.cap = (uint32_t)ctx->cap; lp.cap_next = (uint32_t)ctx->cap_deep; lp.flags = p->flags;
     auto set_level = [&](int level) {
         lp.level = level;
@@ -3164,7 +3254,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         lp.tile_stride = (uint32_t)std::max(1, (cam->tiles_x + cam->world / 2) / std::max(cam->world, 1));
         const TileGrid G(cam->n_slots, lp.tile_stride);
         tiles = G.nblk <= ctx->tile_nblk && G.nreg <= ctx->tile_nreg && G.nzone <= ctx->tile_nzone;
-        if (tiles) ++ctx->tile_frames;
+        ctx->last_tiles = tiles;
     }
     if (s2 > 0 && s2 <= RT_BLOCK) {
         lp.spb = RT_BLOCK / s2;
@@ -3190,7 +3280,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         if (use < 1) use = 1;
         return (ctx->n_cu * use + 7) & ~7;
     };
-    auto shadows = [&](int level, hipStream_t s_, RayQ &qc, HitBuf &hb, SegBuf &sg, BeamBuf &bb, int side) -> int {
+    auto shadows = [&](int level, hipStream_t s_, RayQ &qc, HitBuf &hb, BeamBuf &bb, int side) -> int {
         set_level(level);
         if (ctx->S.n_shadow_lights <= 0) return RT_OK;
         if (beam) {
@@ -3232,11 +3322,10 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
             if (ctx->S.n_prims < 100000 && ctx->env.walk_min != 1) lq.walk_min = 0xffffffffu;
             if (lq.walk_min != 0xffffffffu)
                 hipLaunchKernelGGL(k_shadow_walk, dim3(gsz(ctx->g_walk, ctx->nb_walk, side == 1 ? 3 : side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lq, hb, bb, ctx->ctl);
-            hipLaunchKernelGGL(k_shadow_queue, dim3(gsz(ctx->g_queue, ctx->nb_queue, side == 1 ? 3 : side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lq, qc, hb, sg, bb, ctx->ctl);
+            hipLaunchKernelGGL(k_shadow_queue, dim3(gsz(ctx->g_queue, ctx->nb_queue, side == 1 ? 3 : side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lq, qc, hb, bb, ctx->ctl);
         } else {
-            hipLaunchKernelGGL(k_shadow_setup, dim3(gsz(ctx->g_setup, ctx->nb_setup, side)), block, 0, s_, ctx->S, lp, hb, sg, ctx->ctl);
-            if (fast) hipLaunchKernelGGL(k_shadow<true>, dim3(gsz(ctx->g_shadow, ctx->nb_shadow, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, sg, ctx->ctl);
-            else hipLaunchKernelGGL(k_shadow<false>, dim3(ctx->g_shadow_x), block, 0, s_, ctx->S, ctx->F, lp, qc, hb, sg, ctx->ctl);
+            if (fast) hipLaunchKernelGGL(k_shadow<true>, dim3(gsz(ctx->g_shadow, ctx->nb_shadow, side)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl);
+            else hipLaunchKernelGGL(k_shadow<false>, dim3(ctx->g_shadow_x), block, 0, s_, ctx->S, ctx->F, lp, qc, hb, ctx->ctl);
         }
         return RT_OK;
     };
@@ -3254,10 +3343,10 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                 const TileGrid G(gen->n_slots, lp.tile_stride);
                 to.blockbox = bb.blockbox; to.zcnt = bb.zcnt; to.zrows = G.nzone * (uint32_t)ctx->S.n_shadow_lights;
             }
-            if (fast) hipLaunchKernelGGL((k_intersect<true, true>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side_)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, qn, hb, ctx->ctl, fbx, ids, *gen, bc, side, side2, to);
+            if (fast) hipLaunchKernelGGL((k_intersect<true, true>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side_)), block, ctx->lds_bytes + ctx->lds_top_bytes, s_, ctx->S, ctx->F, lp, qc, qn, hb, ctx->ctl, fbx, ids, *gen, bc, side, side2, to);
             else hipLaunchKernelGGL((k_intersect<false, true>), dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, qn, hb, ctx->ctl, fbx, ids, *gen, bc, side, side2, to);
-        } else if (fast && ctx->F.inv_seg_len > 0.0f) hipLaunchKernelGGL((k_intersect<true, false, true>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side_)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, qn, hb, ctx->ctl, fbx, ids, none, bc, nullptr, nullptr, to);
-        else if (fast) hipLaunchKernelGGL((k_intersect<true, false>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side_)), block, ctx->lds_bytes, s_, ctx->S, ctx->F, lp, qc, qn, hb, ctx->ctl, fbx, ids, none, bc, nullptr, nullptr, to);
+        } else if (fast && ctx->F.inv_seg_len > 0.0f) hipLaunchKernelGGL((k_intersect<true, false, true>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side_)), block, ctx->lds_bytes + ctx->lds_top_bytes, s_, ctx->S, ctx->F, lp, qc, qn, hb, ctx->ctl, fbx, ids, none, bc, nullptr, nullptr, to);
+        else if (fast) hipLaunchKernelGGL((k_intersect<true, false>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side_)), block, ctx->lds_bytes + ctx->lds_top_bytes, s_, ctx->S, ctx->F, lp, qc, qn, hb, ctx->ctl, fbx, ids, none, bc, nullptr, nullptr, to);
         else hipLaunchKernelGGL((k_intersect<false, false>), dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, qn, hb, ctx->ctl, fbx, ids, none, bc, nullptr, nullptr, to);
     };
     auto queue_of = [&](int level) -> RayQ & { return level == 0 ? ctx->q[0] : ctx->q[1 + ((level - 1) & 1)]; };
@@ -3292,7 +3381,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
             intersect(level, st, qc, qn, hb, level == 0 ? fb0 : fbm, 0, bb);
             PROF_MARK(e + 1);
             PROF_MARK(e + 2);
-            if (int rc = shadows(level, st, qc, hb, level == 0 ? ctx->seg : ctx->seg1, bb, 0)) return rc;
+            if (int rc = shadows(level, st, qc, hb, bb, 0)) return rc;
             PROF_MARK(e + 3);
             PROF_MARK(e + 4);
             if (level == 0 && fb0 != ctx->fb) hipLaunchKernelGGL((k_shade<RT_SHADE_LIGHTS | RT_SHADE_STORE>), dim3(ctx->g_shade), block, 0, st, ctx->S, lp, qc, hb, ctx->ctl, fb0, ctx->fb, bb.litbits, bb.pair_slot, bb.queue_n);
@@ -3306,7 +3395,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         HIP_TRY(ctx, hipStreamWaitEvent(s2_, ctx->ev_fork, 0));
         // level 0 (caller's stream) is submitted first: the host needs ~10 us per launch, and the long chain of the
         // deeper levels must not delay the submission of the frame's largest kernel
-        if (int rc = shadows(0, st, ctx->q[0], ctx->hb, ctx->seg, ctx->beam, 1)) return rc;
+        if (int rc = shadows(0, st, ctx->q[0], ctx->hb, ctx->beam, 1)) return rc;
         hipLaunchKernelGGL((k_shade<RT_SHADE_LIGHTS | RT_SHADE_STORE>), dim3(gsz(ctx->g_shade, ctx->nb_shade, 3)), block, 0, st, ctx->S, lp, ctx->q[0], ctx->hb, ctx->ctl, fb0, ctx->fb,
                            ctx->beam.litbits, ctx->beam.pair_slot, ctx->beam.queue_n);
         // deeper levels (stream2): few, long rays - their waves ask for issue priority over the level-0 waves
@@ -3339,7 +3428,6 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                 const bool odd = (level & 1) != 0;
                 const int set = 1 + (level - 1) % nd;
                 HitBuf &hb = *hit_set(*ctx, set);
-                SegBuf &sg = *seg_set(*ctx, set);
                 BeamBuf &bb = *beam_set(*ctx, set);
                 RayQ &qc = pq(level), &qn = pq(level + 1);
                 // set and queue of level - nd are reused: its shading must be through
@@ -3348,7 +3436,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_hit[level], s2_));
                 hipStream_t s3_ = (odd || ctx->env.one_shadow_stream) ? ctx->stream3 : s4_;
                 HIP_TRY(ctx, hipStreamWaitEvent(s3_, ctx->ev_hit[level], 0));
-                if (int rc = shadows(level, s3_, qc, hb, sg, bb, 2)) return rc;
+                if (int rc = shadows(level, s3_, qc, hb, bb, 2)) return rc;
                 if (level >= 2) HIP_TRY(ctx, hipStreamWaitEvent(s3_, ctx->ev_lit[level - 1], 0));
                 hipLaunchKernelGGL(k_shade<RT_SHADE_LIGHTS>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s3_, ctx->S, lp, qc, hb, ctx->ctl, ctx->fb, ctx->fb,
                                    bb.litbits, bb.pair_slot, bb.queue_n);
@@ -3360,7 +3448,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
             for (int level = 1; level <= rec; ++level) {
                 RayQ &qc = queue_of(level), &qn = queue_of(level + 1);
                 intersect(level, s2_, qc, qn, ctx->hb1, fbm, 2, ctx->beam1);
-                if (int rc = shadows(level, s2_, qc, ctx->hb1, ctx->seg1, ctx->beam1, 2)) return rc;
+                if (int rc = shadows(level, s2_, qc, ctx->hb1, ctx->beam1, 2)) return rc;
                 hipLaunchKernelGGL(k_shade<RT_SHADE_LIGHTS>, dim3(gsz(ctx->g_shade, ctx->nb_shade, 2)), block, 0, s2_, ctx->S, lp, qc, ctx->hb1, ctx->ctl, ctx->fb, ctx->fb,
                                    ctx->beam1.litbits, ctx->beam1.pair_slot, ctx->beam1.queue_n);
             }
@@ -3441,7 +3529,7 @@ extern "C" int rt_render_device(rt_ctx *ctx, const rt_render_params *p, float *d
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     uint64_t need = g.slots > g.out_slots ? g.slots : g.out_slots;
-    if (int rc = ensure_frame(ctx, need)) return rc;
+    if (int rc = ensure_frame(ctx, need, ctx->S.n_shadow_lights > 0 ? sh : 0)) return rc;
     const bool prof = (p->flags & RT_FLAG_PROFILE) != 0 && rec >= 0;
     ctx->prof_levels = -1;
     if (prof) { if (int rc = prof_prepare(ctx, rec + 1)) return rc; }
@@ -3478,7 +3566,8 @@ extern "C" int rt_render_device_noalloc(rt_ctx *ctx, const rt_render_params *p, 
     mem.limit = RT_SCRATCH_BYTES;
     FrameState fs;
     if (int rc = mem.get(&fs.ctl, 1)) return rc;
-    if (int rc = carve_frame(ctx, mem, fs, slots, cap, cap, 1.0, 1, 3, false)) {
+    const uint32_t s2n = (uint32_t)(sh * sh);
+    if (int rc = carve_frame(ctx, mem, fs, slots, cap, cap, 1.0, 1.0, (s2n >= 9u && s2n <= RT_BLOCK) ? RT_BLOCK / s2n : RT_BLOCK, 1, 3, false)) {
         char msg[256];
         snprintf(msg, sizeof(msg), "rt_render_device_noalloc: a frame of %llu pixel slots with %d shadow-casting lights does not fit the %llu MiB static scratch buffer",
                  (unsigned long long)slots, ctx->S.n_shadow_lights, (unsigned long long)(RT_SCRATCH_BYTES >> 20));
@@ -3563,7 +3652,8 @@ extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
             uint64_t hist[RT_CUNITS + 2] = {0}, evalp = 0, base = 0;
             for (uint32_t i = 0; i < n; ++i) {
                 float4 u1;
-                if (hipMemcpy(&u1, ctx->beam.rec + (uint64_t)(lst[i] & ((1u << RT_LIST_NU_SHIFT) - 1u)) * RT_PAIR_UNITS + 1, sizeof(u1), hipMemcpyDeviceToHost) != hipSuccess) break;
+                if (lst[i] == RT_LIST_NONE) continue;
+                if (hipMemcpy(&u1, ctx->beam.rec + (uint64_t)i * RT_PAIR_UNITS + 1, sizeof(u1), hipMemcpyDeviceToHost) != hipSuccess) break;
                 uint32_t meta;
                 memcpy(&meta, &u1.w, 4);
                 uint32_t nu = meta & 0xf;
@@ -3577,11 +3667,15 @@ extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
             fprintf(stderr, " | plane0 per ray %.1f%% | own sphere at P %.1f%%\n", 100.0 * evalp / n, 100.0 * base / n);
         }
     }
+    if (!c.overflow && ctx->last_tiles) ++ctx->tile_frames;
+    ctx->last_tiles = false;
     if (c.overflow) {
         // the next frame gets larger queues: the one that ran out
         if (!ctx->last_noalloc) ctx->counters_dirty = true;
         if (ctx->last_noalloc) return fail(ctx, RT_ERR_QUEUE_OVERFLOW, "secondary-ray queue overflow in a no-alloc frame (its queues hold 2 x the pixel slots and cannot grow); nothing valid was written");
-        if (c.overflow_q && ctx->beam_queue_cap < 0x7fffffffu) ctx->qgrowth *= 8.0;
+        if (c.overflow_r && ctx->rec_div <= 1.0) return fail(ctx, RT_ERR_HIP, "pair records ran out although every pair has one");
+        if (c.overflow_r && ctx->rec_div > 1.0) ctx->rec_div = std::max(1.0, ctx->rec_div * 0.5);
+        else if (c.overflow_q && ctx->beam_queue_cap < 0x7fffffffu) ctx->qgrowth *= 8.0;
         else if (c.overflow_deep && ctx->deep_div > 1.0) ctx->deep_div *= 0.5;
         else ctx->growth *= 2.0;
         return fail(ctx, RT_ERR_QUEUE_OVERFLOW, "secondary-ray queue overflow; queue growth factor doubled, render again");
@@ -3728,7 +3822,7 @@ extern "C" int rt_trace(rt_ctx *ctx, const rt_render_params *p, const double *or
     TRY_T(hipMemcpy(d_o, origins, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice));
     TRY_T(hipMemcpy(d_d, directions, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice));
     for (int attempt = 0; attempt < 10; ++attempt) {
-        rc = ensure_frame(ctx, (uint64_t)n);
+        rc = ensure_frame(ctx, (uint64_t)n, ctx->S.n_shadow_lights > 0 ? sh : 0);
         if (rc != RT_OK) break;
         TRY_T(hipEventRecord(ctx->ev0, st));
         TRY_T(hipMemsetAsync(ctx->ctl, 0, sizeof(FrameCtl), st));
@@ -3950,7 +4044,7 @@ extern "C" int rt_initial_rays(rt_ctx *ctx, int width, int height, double *sourc
     std::string why;
     if (int rc = tile_geom(&p, g, why)) return fail(ctx, rc, why);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (int rc = ensure_frame(ctx, g.slots > g.out_slots ? g.slots : g.out_slots)) return rc;
+    if (int rc = ensure_frame(ctx, g.slots > g.out_slots ? g.slots : g.out_slots, 0)) return rc;
     GenParams gp{};
     const rt_scene_desc &s = ctx->host;
     double w = s.cam_screen_width;

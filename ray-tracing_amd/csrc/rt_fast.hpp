@@ -52,7 +52,21 @@ struct FastScene {
     const float *cuts[3];
     int32_t n_cuts[3];
     float inv_seg_len;              // 1 / length of the pieces k_intersect cuts long rays into (0: never cut)
+    // the internal nodes of the first levels once more, breadth first, 16 bytes each {cut bits, axis, left ref, right ref}: the
+    // nearest-hit kernels copy this table into LDS (rt_top_stage) and take the first steps of every descent from there - a
+    // step is a dependent load, ~1 us from L2 / Infinity Cache against ~0.1 us from LDS, and most steps of a short ray are
+    // its first descent.  A ref with RT_TOP_FLAG is an index into this table, any other the node's index in knodes.
+    const uint4 *top;
+    int32_t n_top;                  // 0: no table
 };
+#define RT_TOP_FLAG 0x80000000u
+#define RT_TOP_MAX_NODES 255        // 8 levels, 4 KB of LDS per workgroup
+
+// copy the table into the workgroup's LDS (all threads; ends with a barrier).  ltop: RT_TOP_MAX_NODES entries of dynamic LDS
+__device__ __forceinline__ void rt_top_stage(const FastScene &F, uint4 *ltop) {
+    for (int i = (int)threadIdx.x; i < F.n_top; i += (int)blockDim.x) ltop[i] = F.top[i];
+    __syncthreads();
+}
 
 // Could coordinate v (float64 -> float32) on axis ax be EXACTLY a bound of some node?  A ray that starts in such a plane
 // with an exactly zero direction component along ax is not served by "tree walk == brute force": the reference's slab
@@ -188,28 +202,35 @@ __device__ __forceinline__ bool fast_root_interval(const FastScene &F, const Fas
 // stk: this lane's LDS stack column (stride STRIDE entries).
 template <int STRIDE>
 __device__ __forceinline__ void fast_tree(const DScene &S, const FastScene &F, uint2 *stk, const FastRay &R, d3 o, d3 d, float tmin, float tmax,
-                                          double early_dist, FastState &st) {
+                                          double early_dist, FastState &st, const uint4 *ltop = nullptr) {
     const float of0 = R.of0, of1 = R.of1, of2 = R.of2, ol0 = R.ol0, ol1 = R.ol1, ol2 = R.ol2;
     const float df0 = R.df0, df1 = R.df1, df2 = R.df2, in0 = R.in0, in1 = R.in1, in2 = R.in2;
     const float E0 = R.E0, E1 = R.E1, E2 = R.E2, Emax = R.Emax, af = R.af, dnf = R.dnf;
     tmax = fminf(tmax, st.tbest);
     if (tmin > tmax) return;
-    uint32_t node = 0;
+    uint32_t node = (ltop && F.n_top > 0) ? RT_TOP_FLAG : 0u;
     int sp = 0;
     for (;;) {
-        KNode nd = F.knodes[node];
-        // ---- descend to a leaf, near child first ----
-        while ((nd.b & 3u) != 3u) {
-            const uint32_t ax = nd.b & 3u;
+        KNode nd;
+        // ---- descend to a leaf, near child first (the first levels from the LDS table) ----
+        for (;;) {
+            uint32_t ax, left, right;
+            float cut;
+            if (node & RT_TOP_FLAG) {
+                const uint4 t = ltop[node & ~RT_TOP_FLAG];
+                cut = __uint_as_float(t.x); ax = t.y; left = t.z; right = t.w;
+            } else {
+                nd = F.knodes[node];
+                if ((nd.b & 3u) == 3u) break;
+                cut = __uint_as_float(nd.a); ax = nd.b & 3u; left = node + 1u; right = nd.b >> 2;
+            }
             RT_TS(++st.n_node;)
-            const float cut = __uint_as_float(nd.a);
             const float oa = ax == 0 ? of0 : (ax == 1 ? of1 : of2);
             const float ia = ax == 0 ? in0 : (ax == 1 ? in1 : in2);
             const float ea = ax == 0 ? E0 : (ax == 1 ? E1 : E2);
             const float t = (cut - oa) * ia;
             const float m = fmaf(fabsf(t), RT_2M20, ea);
             const float tl = t - m, th = t + m;
-            const uint32_t left = node + 1, right = nd.b >> 2;
             const bool dneg = ia < 0.0f;      // side the ray comes from, consistent with the sign used for t
             const uint32_t nearc = dneg ? right : left, farc = dneg ? left : right;
             if (tl > tmax) node = nearc;                 // plane beyond the segment: near side only
@@ -220,7 +241,6 @@ __device__ __forceinline__ void fast_tree(const DScene &S, const FastScene &F, u
                 node = nearc;
                 tmax = fminf(tmax, th);
             }
-            nd = F.knodes[node];
         }
         // ---- leaf ----
         {
@@ -313,12 +333,12 @@ __device__ __forceinline__ void fast_tree(const DScene &S, const FastScene &F, u
 // (-inf for ordinary rays).  stk: this lane's LDS stack column (stride STRIDE entries).
 template <int STRIDE>
 __device__ __forceinline__ void fast_nearest(const DScene &S, const FastScene &F, uint2 *stk, d3 o, d3 d, float tlim,
-                                             double early_dist, FastState &st) {
+                                             double early_dist, FastState &st, const uint4 *ltop = nullptr) {
     fast_init(st, tlim);
     const FastRay R = fast_ray(F, o, d);
     fast_planes(S, R, o, d, early_dist, st);
     if (st.stop) return;
     float tmin, tmax;
     if (!fast_root_interval(F, R, st.tbest, tmin, tmax)) return;
-    fast_tree<STRIDE>(S, F, stk, R, o, d, tmin, tmax, early_dist, st);
+    fast_tree<STRIDE>(S, F, stk, R, o, d, tmin, tmax, early_dist, st, ltop);
 }

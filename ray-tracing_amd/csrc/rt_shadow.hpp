@@ -43,12 +43,19 @@ struct CandF {               // decoded candidate
     uint32_t kind;
 };
 struct BeamBuf {
-    float4 *rec;             // [pair][RT_PAIR_UNITS]
+    // Records live in SLOTS, handed out to the pairs that need one (listed pairs: header + candidate units; overflowing pairs:
+    // the header, for k_shadow_walk) - rec_cap of them, a fraction of the pairs (13 % of the pairs of the 10k-sphere scene are
+    // listed); a level that needs more raises FrameCtl::overflow_r and the frame is rendered again with more.  Slots are taken
+    // 64 at a time per wave (one returning atomic on queue_n[1]) and used up in order, so list[] is dense up to the unused tail
+    // of each wave's last block (RT_LIST_NONE there, and at the slots of overflowing pairs).
+    float4 *rec;             // [slot][RT_PAIR_UNITS]
     unsigned long long *queue;   // shadow-ray numbers g the filter could not decide
-    uint32_t *queue_n;       // [0] = queue entries appended, [1] = pairs listed, [2] = pairs in ovlist, [3] = queue capacity
-    uint32_t *ovlist;        // pairs whose rays all go to the float64 kernel (candidate overflow, delicate basis)
-    uint32_t *list;          // [slot] -> pair: the pairs whose rays need the per-ray filter, in no particular order
+    uint32_t *queue_n;       // [0] = queue entries appended, [1] = slots handed out, [2] = pairs in ovlist, [3] = queue capacity
+    unsigned long long *ovlist;  // pairs whose rays all go to the float64 kernel (candidate overflow, delicate basis): pair | slot << 32
+    uint32_t *list;          // [slot] -> pair | units used << 28 of a listed pair (its rays need the per-ray filter), or RT_LIST_NONE
     uint32_t *pair_slot;     // [pair] -> slot, or RT_PAIR_LIT / RT_PAIR_UNLIT when the whole pair is decided
+    uint32_t rec_cap;        // slots in rec / list (a multiple of 64)
+    uint32_t rec_blk;        // slots a wave of k_beam_setup takes at a time (8 .. 64)
     unsigned long long *litbits; // [chunk of slots][wave]: which lanes' rays the filter found lit (every word written per level)
     // tile beams (level 0 of scenes with short beams; set 0 only): candidates per (block of 64 ray slots, shadow light), found by
     // binning the primitives against the union of the block's beams, zone -> region -> block (k_bin_*, rt_amd.hip)
@@ -63,6 +70,7 @@ struct BeamBuf {
 #define RT_ZONE_NC 131072u              // ... a (zone, light) row (or every primitive of a smaller scene)
 #define RT_REGION_BLOCKS 16u            // a region = 4 x 4 blocks (32 x 32 pixels), a zone = 64 regions
 #define RT_TILE_OVERFLOW 0xFFFFFFFFu    // more candidates than the row holds: the pairs concerned walk the tree themselves
+#define RT_LIST_NONE 0xFFFFFFFFu
 #define RT_PAIR_LIT 0xFFFFFFFFu
 #define RT_PAIR_UNLIT 0xFFFFFFFEu
 #define RT_META_OVERFLOW 0xFu
@@ -227,7 +235,8 @@ struct LightQuad {
 
 // Result of the beam traversal of one (hit, light) pair.
 struct BeamOut {
-    uint32_t nu, boxmask;    // candidate units written to out[], which of them start a box
+    uint32_t nu, boxmask;    // candidate units the pair's record needs, which of them start a box
+    uint32_t keep;           // bit k: touched primitive tl[k] is a candidate (beam_write_units writes their units, in this order)
     bool overflow;           // the units do not suffice: every ray of the pair goes to the float64 queue
     bool occ_all;            // one sphere occludes EVERY ray of the pair (traversal stopped there)
     bool atp_all;            // P lies on a sphere that every ray of the pair leaves through P (not stored in out[])
@@ -235,8 +244,9 @@ struct BeamOut {
     uint32_t why;            // diagnostics: 1 touched list full, 2 candidate units full, 3 dedup list full
 };
 
-// c* / h*: centre and half size of the box of all sample origins, relative to P.  out: the pair record's
-// RT_CUNITS candidate units.  Everything here is a conservative float32 filter; the absolute slack E covers the
+// c* / h*: centre and half size of the box of all sample origins, relative to P.  The candidates' units are NOT written here:
+// a pair's record gets its place in memory only once the pair turns out to need one (13 % do), then beam_write_units
+// re-expresses the kept primitives (BeamOut::keep).  Everything here is a conservative float32 filter; the absolute slack E covers the
 // rounding of P, of the cut planes / leaf records and of the differences (<= 6 Kp 2^-24 in all); the candidates
 // it lets through are re-expressed from float64.
 //
@@ -267,10 +277,10 @@ struct TileRow {
 };
 template <int STRIDE, bool EARLY, bool BOXES, bool TILES = false>
 __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene &F, uint2 *stk, uint32_t *tl, d3 P, float cB0, float cB1,
-                                                float cB2, float h0, float h1, float h2, const LightQuad &Q, float4 *out, int dbg,
+                                                float cB2, float h0, float h1, float h2, const LightQuad &Q, int dbg,
                                                 bool on = true, const TileRow *T = nullptr) {
     BeamOut R;
-    R.nu = 0; R.boxmask = 0; R.overflow = false; R.occ_all = false; R.atp_all = false; R.trips = 0; R.why = 0;
+    R.nu = 0; R.boxmask = 0; R.keep = 0; R.overflow = false; R.occ_all = false; R.atp_all = false; R.trips = 0; R.why = 0;
     const float Pf0 = (float)P.x, Pf1 = (float)P.y, Pf2 = (float)P.z;
     const float Kp = fmaxf(fmaxf(fabsf(Pf0), fabsf(Pf1)), fmaxf(fabsf(Pf2), F.extent));
     const float E = Kp * RT_2M19 + 2e-6f;            // absolute slack on every plane position (and the 1e-6 offsets)
@@ -606,19 +616,39 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
         }
         if (store) {
             if (nu + kind > RT_CUNITS) { R.overflow = true; R.why = 2; return R; }          // kind == units needed (sphere 1, box 2)
-            if (sph) {
-                out[nu] = make_float4((float)dx, (float)dy, (float)dz, (float)cd);
-                nu += 1;
-            } else {
-                out[nu] = make_float4(bl0, bl1, bl2, bh0);
-                out[nu + 1] = make_float4(bh1, bh2, 0.0f, 0.0f);
-                boxmask |= 1u << nu;
-                nu += 2;
-            }
+            R.keep |= 1u << k;
+            if (!sph) boxmask |= 1u << nu;
+            nu += kind;
         }
     }
     R.nu = nu; R.boxmask = boxmask;
     return R;
+}
+
+// The candidate units of a listed pair (k_beam_setup, once the pair has its record): the kept primitives of beam_collect,
+// in its order, re-expressed relative to P from their float64 records - sphere {centre - P, |centre - P|^2 - r^2}, box two
+// units {lo - P rounded down, hi - P rounded up}.
+template <int STRIDE, bool BOXES>
+__device__ __forceinline__ void beam_write_units(const DScene &S, const uint32_t *tl, uint32_t keep, d3 P, float4 *out) {
+    uint32_t nu = 0;
+    while (keep) {
+        const uint32_t k = (uint32_t)__builtin_ctz(keep);
+        keep &= keep - 1u;
+        const DPrim *pr = S.prims + tl[k * STRIDE];
+        const bool sph = !BOXES || pr->kind == 1;
+        if (sph) {
+            const double dx = pr->a[0] - P.x, dy = pr->a[1] - P.y, dz = pr->a[2] - P.z;
+            const double cd = ((dx * dx + dy * dy) + dz * dz) - pr->b[0];
+            out[nu] = make_float4((float)dx, (float)dy, (float)dz, (float)cd);
+            nu += 1;
+        } else {
+            const float bl0 = __double2float_rd(pr->a[0] - P.x), bl1 = __double2float_rd(pr->a[1] - P.y), bl2 = __double2float_rd(pr->a[2] - P.z);
+            const float bh0 = __double2float_ru(pr->b[0] - P.x), bh1 = __double2float_ru(pr->b[1] - P.y), bh2 = __double2float_ru(pr->b[2] - P.z);
+            out[nu] = make_float4(bl0, bl1, bl2, bh0);
+            out[nu + 1] = make_float4(bh1, bh2, 0.0f, 0.0f);
+            nu += 2;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

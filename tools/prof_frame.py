@@ -35,7 +35,7 @@ def main():
                              want_rgb=False, want_ids=False)
             ms.append(round(out["stats"]["ms_total"], 3))
         st = out["stats"]
-        print("ms_total per frame:", ms)
+        print("ms_total per frame:", ms, "| frame state %.2f GB" % (ctx.frame_bytes() / 1e9))
         print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()})
 
 
