@@ -269,6 +269,15 @@ inline void pcg3d(uint32_t &x, uint32_t &y, uint32_t &z) {
 }
 /* One hash per shadow ray; the high halves of (x, y, z) are the first draw of Light.py:277, the low halves the
  * second (16 bits per deviate: steps of g / 32768). */
+/* path code of a child ray: the turns as a bit string under a leading 1 down to level 31, a hash of (parent code, turn) kept
+ * above 2^31 beyond - the same function as child_path() in ray-tracing_amd/csrc/rt_device.hpp (restated, not included: the
+ * oracle shares no code with the product) */
+inline uint32_t child_path(uint32_t path, uint32_t mirror) {
+    if (path < 0x80000000u) return path * 2u + mirror;
+    uint32_t h = (path ^ (mirror * 0x85EBCA6Bu + 0x9E3779B1u)) * 0x2C1B3C6Du;
+    h ^= h >> 15; h *= 0x297A2D39u; h ^= h >> 15;
+    return h | 0x80000000u;
+}
 inline void jitter6(uint32_t seed, uint32_t pixel, uint32_t path, uint32_t light, uint32_t sample, double g,
                     double out[6]) {
     uint32_t x = pixel, y = path * 0x9E3779B1u + light, z = seed * 0x85EBCA6Bu + sample;
@@ -407,7 +416,7 @@ V3 trace(const Ctx &cx, V3 o, V3 d, int rec, uint32_t pixel, uint32_t path, Coun
     V3 through{0, 0, 0};
     if (T != 0) {                                                   /* :108-116 */
         V3 o2 = P + EPSILON * d;
-        through = trace(cx, o2, d, rec - 1, pixel, path * 2u, c, nullptr, 1);
+        through = trace(cx, o2, d, rec - 1, pixel, child_path(path, 0u), c, nullptr, 1);
     }
     V3 back = through * Tv;                                         /* :117 */
     V3 refl{0, 0, 0};
@@ -415,7 +424,7 @@ V3 trace(const Ctx &cx, V3 o, V3 d, int rec, uint32_t pixel, uint32_t path, Coun
         double dp = dot(V, Nh);
         V3 Rd = (2 * dp) * Nh - V;
         V3 o2 = P + EPSILON * Rd;
-        refl = trace(cx, o2, Rd, rec - 1, pixel, path * 2u + 1u, c, nullptr, 2);
+        refl = trace(cx, o2, Rd, rec - 1, pixel, child_path(path, 1u), c, nullptr, 2);
     }
     refl = refl * Kr;                                               /* :130 */
     return (back + base) + refl;                                    /* :132 */

@@ -65,7 +65,8 @@ struct FrameCtl {
     uint32_t n_listed[RT_MAX_LEVELS + 2];   // diagnostics: pairs that needed the per-ray filter / rays that needed
     uint32_t n_queued[RT_MAX_LEVELS + 2];   // the float64 queue, per level (copied by k_shade)
     uint32_t n_walked[RT_MAX_LEVELS + 2];   // rays of overflowing pairs (k_shadow_walk)
-    uint32_t dbg_max_trips, dbg_pad;        // RT_FLAG 0x1000: longest / total beam traversal of the frame
+    // diagnostics build only (make stats: -DRT_DIAG; render flag 0x1000 counters, 0x2000 clocks of k_bin_tiles)
+    uint32_t dbg_max_trips, dbg_pad;        // longest / total beam traversal of the frame
     uint32_t dbg_why[4];                    // pairs sent to the queue: delicate basis, touched list, units, dedup list
     unsigned long long dbg_tcyc[4];
     uint32_t dbg_tile[8];                   // flag 0x1000, tile beams: (zone, light) rows / entries, (region, light) rows / entries / overflows, (block, light) rows / entries / overflows
@@ -92,6 +93,7 @@ struct GenParams {
     double hg, wg;
     int32_t W, H, tiles_x, n_tiles, rank, world, tw, th;
     uint32_t n_slots;
+    float rcp_tiles_x;       // 1 / tiles_x (div_small)
 };
 
 struct LevelParams {
@@ -345,7 +347,7 @@ __device__ __forceinline__ bool ray_is_tame(d3 o, d3 d) {
 #ifdef RT_TRAV_STATS
 // diagnostics build only (make stats): per level [rays, node steps, leaf visits, leaf batches, confirmations, max node steps, max leaf visits, max confirmations]
 __device__ unsigned long long g_trav_stats[RT_MAX_LEVELS * 8];
-__device__ unsigned long long g_trav_time[RT_MAX_LEVELS * 8];     // per level: max over waves of wall_clock64 ticks: [0] planes + root, [1] first pieces, [2] further pieces, [3] whole chunk, [4] pieces dealt (sum), [5] rounds (max), [6] exact walks (sum), [7] kernel (max over waves)
+__device__ unsigned long long g_trav_time[RT_MAX_LEVELS * 8];     // per level: [7] = longest wave of k_intersect in wall_clock64 ticks (100 MHz)
 #endif
 // nearest hit, fast path with exact fallback (ties between different primitives, wild rays, non-kd trees)
 template <bool FAST>
@@ -374,15 +376,35 @@ __device__ __forceinline__ Hit nearest_hit(const DScene &S, const FastScene &F, 
 // kernels
 // ------------------------------------------------------------------------------------------------
 // camera ray of queue item k (ray_functions.py:31-41), written to the queue; false for a padding lane.
+// n / d for n < 2^22 (tile numbers) and any d >= 1, rcp = 1 / d in float32: the float quotient (relative error < 2^-22) is off
+// by at most one either way, one correction step makes it exact - ~10 instructions against ~40 (32-bit) or ~100 (64-bit) of
+// the general integer division, four of which a camera ray used to need
+__device__ __forceinline__ uint32_t div_small(uint32_t n, uint32_t d, float rcp, uint32_t &rem) {
+    uint32_t q = (uint32_t)((float)n * rcp);
+    int32_t r = (int32_t)n - (int32_t)(q * d);
+    if (r < 0) { --q; r += (int32_t)d; }
+    else if (r >= (int32_t)d) { ++q; r -= (int32_t)d; }
+    rem = (uint32_t)r;
+    return q;
+}
 // FULL = false (the fused camera-ray pass): origin and throughput stay unwritten - nobody traces the ray again, and
 // k_shade knows that a camera ray starts with throughput 1 (LevelParams::unit_thr): 48 of 190 bytes per pixel less.
 template <bool FULL>
-__device__ __forceinline__ bool gen_ray(const GenParams &g, const RayQ &q, uint64_t k, d3 &o, d3 &dn, uint32_t &slot, bool store = true) {
-    uint32_t tile_local = (uint32_t)(k / (uint32_t)(g.tw * g.th));
-    uint32_t lane = (uint32_t)(k % (uint32_t)(g.tw * g.th));
+__device__ __forceinline__ bool gen_ray(const GenParams &g, const RayQ &q, uint64_t k, d3 &o, d3 &dn, uint32_t &slot) {
+    uint32_t tile_local, lane, lx, ly;
+    const uint32_t k32 = (uint32_t)k;                 // (n_slots < 2^32)
+    if (g.tw == 8 && g.th == 8) { tile_local = k32 >> 6; lane = k32 & 63u; lx = lane & 7u; ly = lane >> 3; }
+    else {
+        tile_local = k32 / (uint32_t)(g.tw * g.th);
+        lane = k32 - tile_local * (uint32_t)(g.tw * g.th);
+        ly = lane / (uint32_t)g.tw; lx = lane - ly * (uint32_t)g.tw;
+    }
     uint32_t tile = g.world > 1 ? (uint32_t)g.rank + tile_local * (uint32_t)g.world : tile_local;
-    int x = (int)(tile % (uint32_t)g.tiles_x) * g.tw + (int)(lane % (uint32_t)g.tw);
-    int y = (int)(tile / (uint32_t)g.tiles_x) * g.th + (int)(lane / (uint32_t)g.tw);
+    uint32_t tx, ty;
+    if (tile < (1u << 22)) ty = div_small(tile, (uint32_t)g.tiles_x, g.rcp_tiles_x, tx);
+    else { ty = tile / (uint32_t)g.tiles_x; tx = tile - ty * (uint32_t)g.tiles_x; }
+    int x = (int)tx * g.tw + (int)lx;
+    int y = (int)ty * g.th + (int)ly;
     bool valid = tile < (uint32_t)g.n_tiles && x < g.W && y < g.H;
     if (!valid) {
         q.slot[k] = RT_INVALID_SLOT;
@@ -397,12 +419,10 @@ __device__ __forceinline__ bool gen_ray(const GenParams &g, const RayQ &q, uint6
     if (FULL) { q.ox[k] = pos.x; q.oy[k] = pos.y; q.oz[k] = pos.z; q.tr[k] = 1.0; q.tg[k] = 1.0; q.tb[k] = 1.0; }
     uint32_t gp = (uint32_t)y * (uint32_t)g.W + (uint32_t)x;
     slot = g.world > 1 ? (uint32_t)k : gp;
-    if (store) {
-        q.dx[k] = dn.x; q.dy[k] = dn.y; q.dz[k] = dn.z;
-        q.slot[k] = slot;
-        q.gpix[k] = gp;
-        q.path[k] = 1u;
-    }
+    q.dx[k] = dn.x; q.dy[k] = dn.y; q.dz[k] = dn.z;
+    q.slot[k] = slot;
+    q.gpix[k] = gp;
+    q.path[k] = 1u;
     return true;
 }
 
@@ -543,21 +563,11 @@ struct TileOut {
     uint32_t zrows;
 };
 
-#define RT_SEG_MAX 16u        // pieces a long ray is cut into at most (k_intersect)
-__device__ __forceinline__ float seg_start(float rmin, float seg, uint32_t k) { return fmaf((float)k, seg, rmin); }
-
 // Nearest hit of every queued ray; miss -> background, hit -> hit record + compacted hit list + the hit's children appended to
 // the next level's queue.
 // GEN (level 0 of a frame): the camera rays are made here and written to the queue on the way - their stores
 // overlap the traversal instead of costing a launch of their own (k_gen) before it.
-// !GEN, long rays in pieces: a level >= 1 holds few rays, some of them long (a reflection skimming over the field crosses 60
-// leaves where the average ray crosses 3), and the kernel lasts as long as its longest lane.  A ray's part inside the root box
-// is cut into K <= RT_SEG_MAX pieces of F.seg_len; lane = ray walks the first piece, and the pieces still needed afterwards
-// (those that start before the best hit so far) are dealt to the lanes of the wave, 64 at a time, each walked like a ray of
-// its own - any sub-range of the ray parameter may be walked separately, fast_tree tests every primitive of a visited leaf
-// whole - and merged back by their ray's lane: strictly smaller float64 distance wins, equal distances of different
-// primitives (and ties inside a piece) send the ray to the reference-order walk, as in nearest_hit.
-template <bool FAST, bool GEN, bool SEG = false>
+template <bool FAST, bool GEN>
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) k_intersect(DScene S, FastScene F, LevelParams lp, RayQ q, RayQ qn, HitBuf hb,
                                                         FrameCtl *ctl, double *fb, int32_t *ids_out, GenParams gp, uint32_t *beam_counters,
                                                         double *fb_side, double *fb_side2, TileOut to) {
@@ -609,10 +619,10 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
             // every output slot is visited exactly once here: the framebuffers are initialised by plain stores
             // (fb: 0 or the background of a miss, below; fb_side: 0) instead of two memsets before the frame
             const bool in_range = active;
-            if (active) active = gen_ray<false>(gp, q, k, o, d, slot, !(lp.flags & 0x8000));
+            if (active) active = gen_ray<false>(gp, q, k, o, d, slot);
             valid_total += active ? 1ull : 0ull;
             const uint32_t zs = active ? slot : ((in_range && gp.world > 1) ? (uint32_t)k : RT_INVALID_SLOT);
-            if (zs != RT_INVALID_SLOT && !(lp.flags & 0x4000)) {
+            if (zs != RT_INVALID_SLOT) {
                 if (!active) { fb[3ull * zs] = 0.0; fb[3ull * zs + 1] = 0.0; fb[3ull * zs + 2] = 0.0; }
                 if (fb_side) { fb_side[3ull * zs] = 0.0; fb_side[3ull * zs + 1] = 0.0; fb_side[3ull * zs + 2] = 0.0; }
                 if (fb_side2) { fb_side2[3ull * zs] = 0.0; fb_side2[3ull * zs + 1] = 0.0; fb_side2[3ull * zs + 2] = 0.0; }
@@ -628,127 +638,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
         // the nearest hit; hid: its id, hp: its point (also stored to the hit record as soon as it is known)
         int32_t hid = 0;
         d3 hp = mk3(dnan(), dnan(), dnan());
-        if (FAST && !GEN && SEG) {
-            // ---- long rays in pieces (all 64 lanes stay together: the pieces are dealt with wave shuffles).  Registers are the
-            // limit here (128, so that a workgroup of this kernel fits beside three of the level-0 side): a ray's origin and
-            // direction are read again from the queue where they are needed after the walk, and the hit point of the best
-            // hit so far lives in the hit record, not in registers
-            const float inf = __int_as_float(0x7f800000);
-            const bool tame = active && ray_is_tame(o, d);
-            const bool exact = active && !tame;
-#ifdef RT_TRAV_STATS
-            const long long tc0 = wall_clock64();
-#endif
-            FastState acc;
-            fast_init(acc, inf);
-            float rmin = 0.0f, rmax = -1.0f, seg = 0.0f;
-            uint32_t K = 0u;
-            if (tame) {
-                const FastRay R0 = fast_ray(F, o, d);
-                fast_planes(S, R0, o, d, -dinf(), acc);
-                if (fast_root_interval(F, R0, acc.tbest, rmin, rmax)) {
-                    const float pieces = ceilf((rmax - rmin) * R0.dnf * F.inv_seg_len);
-                    K = pieces >= 2.0f ? (pieces < (float)RT_SEG_MAX ? (uint32_t)pieces : RT_SEG_MAX) : 1u;      // (NaN: 1 piece)
-                    seg = (rmax - rmin) / (float)K;
-                    if (!(seg > 0.0f) || !(seg < inf)) K = 1u;
-                }
-            }
-#ifdef RT_TRAV_STATS
-            const long long tc1 = wall_clock64();
-#endif
-            // round 0: the lane's own ray, first piece
-            if (K > 0u) {
-                const FastRay R = fast_ray(F, o, d);
-                fast_tree<RT_BLOCK>(S, F, stk, R, o, d, rmin, K > 1u ? seg_start(rmin, seg, 1u) : rmax, -dinf(), acc, ltop);
-            }
-            if (acc.best.id != 0) { hb.px[k] = acc.best.p.x; hb.py[k] = acc.best.p.y; hb.pz[k] = acc.best.p.z; }
-            double best_dist = acc.best.dist;
-            int32_t best_id = acc.best.id;
-            float best_tb = acc.tbest;
-            bool tie = acc.tie;
-            // pieces 1 .. K - 1 that start before the best hit so far (one too many is harmless: it ends at once)
-            uint32_t n_extra = 0u;
-            if (K > 1u) {
-                const float cap = fminf(rmax, best_tb);
-                if (cap > seg_start(rmin, seg, 1u)) {
-                    const float kf = floorf((cap - rmin) / seg) + 1.0f;
-                    n_extra = kf < (float)(K - 1u) ? (uint32_t)kf : K - 1u;
-                }
-            }
-            uint32_t incl = n_extra;
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t v = (uint32_t)__shfl_up((int)incl, off);
-                if (lane >= off) incl += v;
-            }
-            const uint32_t total = (uint32_t)__shfl((int)incl, 63);
-#ifdef RT_TRAV_STATS
-            const long long tc2 = wall_clock64();
-#endif
-            for (uint32_t base = 0u; base < total; base += 64u) {
-                // this lane's piece: piece `kseg` of the ray of lane `src`
-                const uint32_t item = base + (uint32_t)lane;
-                const bool have = item < total;
-                int src = 0;                         // number of lanes whose inclusive count is <= item
-                for (int step = 32; step >= 1; step >>= 1) {
-                    const uint32_t v = (uint32_t)__shfl((int)incl, src + step - 1);
-                    if (v <= item) src += step;
-                }
-                src &= 63;
-                const uint32_t s_incl = (uint32_t)__shfl((int)incl, src), s_extra = (uint32_t)__shfl((int)n_extra, src), s_K = (uint32_t)__shfl((int)K, src);
-                const uint32_t kseg = item - (s_incl - s_extra) + 1u;
-                const float s_rmin = __shfl(rmin, src), s_rmax = __shfl(rmax, src), s_seg = __shfl(seg, src);
-                const float tb = __shfl(best_tb, src);
-                const float t0 = seg_start(s_rmin, s_seg, kseg);
-                const float t1 = kseg + 1u >= s_K ? s_rmax : seg_start(s_rmin, s_seg, kseg + 1u);
-                // the ray itself: straight from the queue (the source lane's registers do not keep it)
-                const uint32_t s_k = (uint32_t)__shfl((int)(uint32_t)k, src);
-                FastState st;
-                fast_init(st, tb);
-                if (have) {
-                    const d3 io = mk3(q.ox[s_k], q.oy[s_k], q.oz[s_k]), idv = mk3(q.dx[s_k], q.dy[s_k], q.dz[s_k]);
-                    const FastRay R = fast_ray(F, io, idv);
-                    fast_tree<RT_BLOCK>(S, F, stk, R, io, idv, t0, t1, -dinf(), st, ltop);
-                }
-                // merge: the pieces of this lane's ray sit in lanes [a, a + run) of this round
-                const uint32_t excl = incl - n_extra;
-                const uint32_t lo = excl > base ? excl : base, hi = incl < base + 64u ? incl : base + 64u;
-                const uint32_t run = hi > lo ? hi - lo : 0u, a = lo - base;
-                int win = -1;
-                for (uint32_t jj = 0; __any(jj < run); ++jj) {
-                    const int idx = (int)((a + jj) & 63u);
-                    const double dj = __shfl(st.best.dist, idx);
-                    const int idj = __shfl(st.best.id, idx), tiej = __shfl((int)st.tie, idx);
-                    const float tbj = __shfl(st.tbest, idx);
-                    if (jj < run) {
-                        if (tiej) tie = true;
-                        if (dj < best_dist) { best_dist = dj; best_id = idj; best_tb = tbj; win = idx; }
-                        else if (dj == best_dist && idj != best_id && idj != 0) tie = true;
-                    }
-                }
-                const int wl = win >= 0 ? win : 0;
-                const double wx = __shfl(st.best.p.x, wl), wy = __shfl(st.best.p.y, wl), wz = __shfl(st.best.p.z, wl);
-                if (win >= 0) { hb.px[k] = wx; hb.py[k] = wy; hb.pz[k] = wz; }
-            }
-#ifdef RT_TRAV_STATS
-            {
-                const long long tc3 = wall_clock64();
-                unsigned long long *tt = g_trav_time + 8 * lp.level;
-                if (lane == 0) {
-                    atomicMax(tt + 0, (unsigned long long)(tc1 - tc0)); atomicMax(tt + 1, (unsigned long long)(tc2 - tc1)); atomicMax(tt + 2, (unsigned long long)(tc3 - tc2));
-                    atomicAdd(tt + 4, (unsigned long long)total); atomicMax(tt + 5, (unsigned long long)((total + 63u) / 64u));
-                }
-                if (active && (exact || tie)) atomicAdd(tt + 6, 1ull);
-            }
-#endif
-            if (active) {
-                hid = best_id;
-                if (exact || tie) {
-                    const Hit h = nearest_hit_exact(S, mk3(q.ox[k], q.oy[k], q.oz[k]), mk3(q.dx[k], q.dy[k], q.dz[k]));
-                    hid = h.id;
-                    if (hid != 0) { hb.px[k] = h.p.x; hb.py[k] = h.p.y; hb.pz[k] = h.p.z; }
-                }
-            }
-        } else if (active) {
+        if (active) {
             const Hit h = nearest_hit<FAST>(S, F, stk, o, d, lp.level, ltop);
             hid = h.id;
             hp = h.p;
@@ -1017,7 +907,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bin_tiles(DScene S, FastScene F, L
     const uint32_t nsl = (uint32_t)S.n_shadow_lights, zcap = min((uint32_t)S.n_prims, RT_ZONE_NC), rows = G.nreg * nsl;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t row = blockIdx.x; row < rows; row += gridDim.x) {
+#ifdef RT_DIAG
         const long long tc0 = wall_clock64();
+#endif
         const uint32_t reg = row / nsl, ml = row - reg * nsl;
         // the zone's list: its length and the lane's first two entries are requested before anything else of the row
         const uint32_t zrow = G.zone_of(reg) * nsl + ml;
@@ -1033,7 +925,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bin_tiles(DScene S, FastScene F, L
         __syncthreads();                 // (the last readers of the counter and of the records are through)
         if (threadIdx.x == 0) cnt = 0u;
         __syncthreads();
+#ifdef RT_DIAG
         const long long tc1 = wall_clock64();
+#endif
         bool over = B.ok && (zc > zcap || B.wild);
         if (B.ok && !over) {
             for (uint32_t i0 = 0; i0 < zn; i0 += 2u * RT_BLOCK) {
@@ -1060,13 +954,15 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bin_tiles(DScene S, FastScene F, L
             }
         }
         __syncthreads();
-        const long long tc2 = wall_clock64();
         const uint32_t rn = cnt;
         over = over || rn > RT_REGION_NC;
+#ifdef RT_DIAG
+        const long long tc2 = wall_clock64();
         if ((lp.flags & 0x1000) && threadIdx.x == 0 && B.ok) {
             atomicAdd(&ctl->dbg_tile[1], zn);
             atomicAdd(&ctl->dbg_tile[2], 1u); atomicAdd(&ctl->dbg_tile[3], min(rn, RT_REGION_NC)); if (over) atomicAdd(&ctl->dbg_tile[4], 1u);
         }
+#endif
         {
             // a wave takes 4 of the region's blocks at once: 16 lanes per block, 16 records per step
             const uint32_t sub = (uint32_t)lane >> 4, li = (uint32_t)lane & 15u, j = (uint32_t)wave * 4u + sub;
@@ -1103,18 +999,22 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bin_tiles(DScene S, FastScene F, L
             if (blk != 0xffffffffu && li == 0u) {
                 const uint32_t cf = !Bb.ok ? 0u : (over ? RT_TILE_OVERFLOW : c);
                 bb.tcnt[trow] = cf;
+#ifdef RT_DIAG
                 if ((lp.flags & 0x1000) && Bb.ok) {
                     atomicAdd(&ctl->dbg_tile[5], 1u);
                     if (cf == RT_TILE_OVERFLOW) atomicAdd(&ctl->dbg_tile[7], 1u); else atomicAdd(&ctl->dbg_tile[6], cf);
                 }
+#endif
             }
         }
+#ifdef RT_DIAG
         if ((lp.flags & 0x2000) && threadIdx.x == 0) {
             const long long tc3 = wall_clock64();
             atomicAdd(&ctl->dbg_tcyc[0], (unsigned long long)(tc1 - tc0)); atomicAdd(&ctl->dbg_tcyc[1], (unsigned long long)(tc2 - tc1));
             atomicAdd(&ctl->dbg_tcyc[2], (unsigned long long)(tc3 - tc2)); atomicMax(&ctl->dbg_tcyc[3], (unsigned long long)(tc3 - tc0));
             atomicMax(&ctl->dbg_tile[0], zn);
         }
+#endif
     }
 }
 
@@ -1245,8 +1145,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
             BeamOut bo;
             bo.nu = 0; bo.boxmask = 0; bo.keep = 0; bo.overflow = true; bo.occ_all = false; bo.atp_all = false; bo.trips = 0; bo.why = 0;
             if (!delicate || TILES) {
-                if (!TILES && (lp.flags & 0x100)) bo.overflow = false;   // timing experiment only
-                else {
+                {
                     LightQuad Q;
                     Q.u0 = u0; Q.u1 = u1; Q.u2 = u2; Q.r0 = r0; Q.r1 = r1; Q.r2 = r2;
                     const float ur = fabsf(u0 * r0) + fabsf(u1 * r1) + fabsf(u2 * r2);
@@ -1258,7 +1157,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                         const float Rs = tile_light_half(radius, g);
                         const float lim0 = Rs + RT_2M17 * (fabsf(cB0) + Rs) + 1e-5f, lim1 = Rs + RT_2M17 * (fabsf(cB1) + Rs) + 1e-5f, lim2 = Rs + RT_2M17 * (fabsf(cB2) + Rs) + 1e-5f;
                         if (h0 <= lim0 && h1 <= lim1 && h2 <= lim2) T.row = (r >> 6) * nsl + ml;
-                        const bool active = valid && !delicate && !(lp.flags & 0x100);      // (0x100: timing experiment only)
+                        const bool active = valid && !delicate;
                         bo = beam_collect<RT_BLOCK, EARLY, BOXES, true>(S, F, bs, tl_all + threadIdx.x, P, cB0, cB1, cB2, h0, h1, h2, Q, lp.flags, active, &T);
                         if (delicate) bo.overflow = true;
                     } else
@@ -1272,10 +1171,12 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                 for (uint32_t j = 0; j < RT_TOUCH; ++j) printf("[setup] touched[%u] = prim %u\n", j, tl_all[j * RT_BLOCK + threadIdx.x]);
             }
 #endif
+#ifdef RT_DIAG
             if (valid && (lp.flags & 0x1000)) {
                 atomicMax(&ctl->dbg_max_trips, bo.trips); atomicAdd(&ctl->dbg_sum_trips, (unsigned long long)bo.trips);
                 if (bo.overflow) atomicAdd(&ctl->dbg_why[delicate ? 0 : bo.why], 1u);
             }
+#endif
             // every |sample - P| inside the per-ray filter's range (k_shadow_beam: 1e-4 < nv < 1e7)
             const float sc = __builtin_amdgcn_sqrtf(fmaf(cB0, cB0, fmaf(cB1, cB1, cB2 * cB2))), sh = __builtin_amdgcn_sqrtf(fmaf(h0, h0, fmaf(h1, h1, h2 * h2)));
             const bool range_ok = sc - sh > 1.1e-3f && sc + sh < 0.9e6f;
@@ -1530,11 +1431,11 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
         const bool active = ent != NONE;
         const uint32_t seg = ent & ((1u << RT_LIST_NU_SHIFT) - 1u);
         bool lit = false, unsure = false;
-        if (active && !(lp.flags & 0x200)) {
+        if (active) {
             const float4 h0 = rec[0], h1 = rec[1], h2 = rec[2], h3 = rec[3];
             const float g = h0.w;
             const uint32_t meta = __float_as_uint(h1.w);
-            const uint32_t nu = (lp.flags & 0x400) ? 0u : meta & 0xfu, boxmask = (meta >> 4) & 0xfffu;
+            const uint32_t nu = meta & 0xfu, boxmask = (meta >> 4) & 0xfffu;
             if (nu == RT_META_OVERFLOW) unsure = true;
             else {
                 float j10 = 0, j11 = 0, j12 = 0, j20 = 0, j21 = 0, j22 = 0;   // Light.py:277-278: one deviation per component
@@ -1598,7 +1499,6 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow_beam(DScene S, LevelParams 
             }
         }
         // undecided rays -> wave buffer -> queue
-        if (lp.flags & 0x800) unsure = false;       // timing experiment only
         const unsigned long long um = __ballot(unsure);
         if (um) {
             if (unsure) qbuf[qn + (uint32_t)__popcll(um & ((1ull << lane) - 1ull))] = (unsigned long long)seg * s2 + kk;
@@ -2021,7 +1921,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_small_level(DScene S, SmallLayout 
                     qn.ox[w] = o_t.x; qn.oy[w] = o_t.y; qn.oz[w] = o_t.z;
                     qn.dx[w] = d_t.x; qn.dy[w] = d_t.y; qn.dz[w] = d_t.z;
                     qn.tr[w] = thr_t.x; qn.tg[w] = thr_t.y; qn.tb[w] = thr_t.z;
-                    qn.slot[w] = slot; qn.gpix[w] = gpix; qn.path[w] = path * 2u;
+                    qn.slot[w] = slot; qn.gpix[w] = gpix; qn.path[w] = child_path(path, 0u);
                     w++;
                     n_trans++;
                 }
@@ -2029,7 +1929,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_small_level(DScene S, SmallLayout 
                     qn.ox[w] = o_r.x; qn.oy[w] = o_r.y; qn.oz[w] = o_r.z;
                     qn.dx[w] = d_r.x; qn.dy[w] = d_r.y; qn.dz[w] = d_r.z;
                     qn.tr[w] = thr_r.x; qn.tg[w] = thr_r.y; qn.tb[w] = thr_r.z;
-                    qn.slot[w] = slot; qn.gpix[w] = gpix; qn.path[w] = path * 2u + 1u;
+                    qn.slot[w] = slot; qn.gpix[w] = gpix; qn.path[w] = child_path(path, 1u);
                     n_refl++;
                 }
             }
@@ -2228,41 +2128,34 @@ struct FrameState {
 static HitBuf *hit_set(FrameState &fs, int set) { HitBuf *a[5] = {&fs.hb, &fs.hb1, &fs.hb2, &fs.hb3, &fs.hb4}; return a[set]; }
 static BeamBuf *beam_set(FrameState &fs, int set) { BeamBuf *a[5] = {&fs.beam, &fs.beam1, &fs.beam2, &fs.beam3, &fs.beam4}; return a[set]; }
 
-// RT_AMD_* environment switches (diagnostics / experiments), read ONCE in rt_create: a frame takes ~2 ms, a getenv per
-// launch decision is host time on its critical path
+// RT_AMD_* environment switches, read ONCE in rt_create (a frame takes ~2 ms, a getenv per launch decision is host time on its
+// critical path).  What is left are the switches the tests and tools use to force a path the defaults choose by scene or frame:
+//   RT_AMD_DEBUG            per-level diagnostics on stderr
+//   RT_AMD_SETS             buffer sets (1, 2, 3 or 5): fewer sets -> levels share sets and run in sequence
+//   RT_AMD_NO_PIPELINE      deeper levels on one stream
+//   RT_AMD_WALK_MIN         k_shadow_walk takes a level's rays of overflowing pairs from this many on (1 = always, -1 = never)
+//   RT_AMD_BEAM_EARLY       0 | 1: beam walk near side first with the umbra test (default: scenes of >= 100 k primitives)
+//   RT_AMD_TILES_MIN(_PRIMS) tile beams for frames of at least this many camera rays / scenes of at least this many primitives
+//   RT_AMD_CREATE_THREADS   host threads of rt_create's table loops;  RT_AMD_PARSE_THREADS (rt_scene.cpp)
 struct EnvCfg {
-    long long walk_min = 3ll << 20;     // RT_AMD_WALK_MIN: k_shadow_walk takes a level's rays of overflowing pairs from this many on (1 = always, -1 = never)
-    int beam_early = -1;                // RT_AMD_BEAM_EARLY = 0 | 1 (default: by scene size)
-    bool box_kernels = false;           // RT_AMD_BOX_KERNELS: box-capable kernel templates even without boxes
-    bool no_prio = false, prio = false; // RT_AMD_NO_PRIO / RT_AMD_PRIO: wave priority of the deeper levels
-    bool no_pipeline = false;           // RT_AMD_NO_PIPELINE: deeper levels on one stream
-    bool no_tiles = false;              // RT_AMD_NO_TILES: every pair walks the tree itself (no tile beams)
-    long long tiles_min = 1500000;      // RT_AMD_TILES_MIN: tile beams for frames of at least this many camera rays (the three small
-                                        // kernels in front of k_beam_setup cost more than they save on smaller frames)
-    int bin_wgs = 0;                    // RT_AMD_BIN_WGS: workgroups per CU of the binning kernels (default: by schedule and frame size)
-    int tiles_min_prims = 256;          // RT_AMD_TILES_MIN_PRIMS: ... in scenes of at least this many primitives (tile_scene_ok)
-    bool one_shadow_stream = false;     // RT_AMD_ONE_SHADOW_STREAM: soft shadows of all deeper levels on stream3 (diagnostic)
-    bool debug = false;                 // RT_AMD_DEBUG: per-level diagnostics on stderr
-    bool exact = false;                 // RT_AMD_EXACT: batched queries through the reference-order walk
-    int ovl_main = 3, ovl_side = 1, ovl_main2 = 3;   // RT_AMD_OVL_*: workgroups per CU of the two sides of an overlapped frame
+    long long walk_min = 3ll << 20;
+    int beam_early = -1;
+    bool no_pipeline = false;
+    long long tiles_min = 1500000;      // (the three small kernels in front of k_beam_setup cost more than they save on smaller frames)
+    int tiles_min_prims = 256;          // (tile_scene_ok)
+    bool debug = false;
     void read() {
         if (const char *e = getenv("RT_AMD_WALK_MIN")) walk_min = atoll(e);
         if (const char *e = getenv("RT_AMD_BEAM_EARLY")) beam_early = atoi(e) != 0;
-        box_kernels = getenv("RT_AMD_BOX_KERNELS") != nullptr;
-        no_prio = getenv("RT_AMD_NO_PRIO") != nullptr; prio = getenv("RT_AMD_PRIO") != nullptr;
         no_pipeline = getenv("RT_AMD_NO_PIPELINE") != nullptr;
-        one_shadow_stream = getenv("RT_AMD_ONE_SHADOW_STREAM") != nullptr;
-        no_tiles = getenv("RT_AMD_NO_TILES") != nullptr;
         if (const char *v = getenv("RT_AMD_TILES_MIN")) tiles_min = atoll(v);
         if (const char *v = getenv("RT_AMD_TILES_MIN_PRIMS")) tiles_min_prims = atoi(v);
-        if (const char *v = getenv("RT_AMD_BIN_WGS")) bin_wgs = std::max(1, std::min(16, atoi(v)));
         debug = getenv("RT_AMD_DEBUG") != nullptr;
-        exact = getenv("RT_AMD_EXACT") != nullptr;
-        if (const char *e = getenv("RT_AMD_OVL_MAIN")) ovl_main = atoi(e);
-        if (const char *e = getenv("RT_AMD_OVL_SIDE")) ovl_side = atoi(e);
-        if (const char *e = getenv("RT_AMD_OVL_MAIN2")) ovl_main2 = atoi(e);
     }
 };
+// workgroups per CU of the two sides of an overlapped frame (of a CU's four 128-register slots): level-0 side / deeper levels
+#define RT_OVL_MAIN 3
+#define RT_OVL_SIDE 1
 
 struct rt_ctx : FrameState {
     int device = 0;
@@ -2666,8 +2559,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
         }
         {
             // first levels, breadth first (rt_fast.hpp: FastScene::top)
-            int levels = 8;
-            if (const char *e = getenv("RT_AMD_TOP_LEVELS")) levels = atoi(e);
+            const int levels = 8;      // (255 nodes, 4 KB: the camera-ray pass keeps its four workgroups per CU)
             std::vector<uint4> top;
             if (ok && levels > 0 && s->node_right[0] >= 0) {
                 std::vector<int> order, lvl, pos(nn, -1);      // internal nodes of depth < levels, breadth first
@@ -2705,19 +2597,6 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
             ext = fmaxf(ext, fmaxf(fabsf(ctx->F.root_lo[k]), fabsf(ctx->F.root_hi[k])));
         }
         ctx->F.extent = ext * 1.000001f;
-        {
-            // pieces of long rays (k_intersect): RT_AMD_SEG_LEAVES (default 8, 0 = never cut) times the edge of a cube that holds
-            // one leaf's share of the root box - what a ray crosses per leaf, roughly
-            double vol = 1.0;
-            for (int k = 0; k < 3; ++k) vol *= std::max(s->node_hi[k] - s->node_lo[k], 1e-30);
-            int n_leaves = 0;
-            for (int i = 0; i < nn; ++i) n_leaves += s->node_right[i] < 0 ? 1 : 0;
-            const double leaf_edge = cbrt(vol / (double)std::max(n_leaves, 1));
-            double per = 0.0;
-            if (const char *e = getenv("RT_AMD_SEG_LEAVES")) per = atof(e);
-            const double seg_len = per * leaf_edge;
-            ctx->F.inv_seg_len = (per > 0.0 && seg_len > 0.0 && std::isfinite(seg_len)) ? (float)(1.0 / seg_len) : 0.0f;
-        }
         ctx->F.depth = max_depth;
         ctx->F.ok = ok ? 1 : 0;
         ctx->lds_bytes = ok ? (size_t)std::max(max_depth, 2) * RT_BLOCK * sizeof(uint2) : 0;     // (>= 2 rows: k_beam_setup stages tile rows there)
@@ -2725,7 +2604,6 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
             // per-lane stacks can exceed the default 64 KB dynamic-LDS limit on deep trees
             const int big = 160 * 1024;
             HIP_C(hipFuncSetAttribute((const void *)&k_intersect<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 8192));   // 5 KB of static LDS (hit and child buffers)
-            HIP_C(hipFuncSetAttribute((const void *)&k_intersect<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 8192));
             HIP_C(hipFuncSetAttribute((const void *)&k_intersect<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 12288));   // 8 KB of static LDS (hit and child buffers)
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
             HIP_C(hipFuncSetAttribute((const void *)&k_shadow_queue, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -2747,13 +2625,11 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
     // ---- grid = exactly the workgroups that are resident at once (every kernel walks its queue with a fixed
     // grid; a second, partially filled round of workgroups would run at a fraction of the occupancy) ----
     {
-        const char *ov = getenv("RT_AMD_BLOCKS_PER_CU");
         int last_nb = 1;
         auto grid_for = [&](const void *fn, size_t lds) {
             int nb = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, RT_BLOCK, lds) != hipSuccess || nb < 1) nb = 1;
             if (nb > 6) nb = 6;       // ~100 SGPRs per wave admit 6 workgroups of 256 per CU (MI355X_MICROARCH.md, residency)
-            if (ov && atoi(ov) > 0) nb = atoi(ov);
             last_nb = nb;
             int g = ctx->n_cu * nb;
             return (g + 7) & ~7;
@@ -2846,7 +2722,7 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
         L.total = off;
         const size_t raw = (size_t)s->n_planes * sizeof(DPlane) + (size_t)nn * sizeof(DNode) + (size_t)(ns + nb) * sizeof(DPrim) +
                            (size_t)s->n_surfaces * sizeof(DSurf);
-        ctx->small_ok = raw <= RT_SMALL_LDS_MAX && off <= RT_SMALL_LDS_MAX && !getenv("RT_AMD_NO_SMALL");
+        ctx->small_ok = raw <= RT_SMALL_LDS_MAX && off <= RT_SMALL_LDS_MAX;
         if (ctx->small_ok) {
             int nbk = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, (const void *)&k_small_level<true>, RT_BLOCK, L.total) != hipSuccess || nbk < 1) nbk = 1;
@@ -2856,7 +2732,6 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
         if (ctx->env.debug) fprintf(stderr, "[rt_amd] small-scene path: %s (%u B of tables), grid %d\n", ctx->small_ok ? "on" : "off", L.total, ctx->g_small);
     }
     if (const char *lim = getenv("RT_AMD_SETS")) ctx->env_sets = atoi(lim);      // 1, 2 or 3 buffer sets (diagnostic)
-    if (getenv("RT_AMD_ONE_SET")) ctx->env_sets = 1;
     ctx->host = *s;   // pointers inside are NOT used after this call; scalars (camera, settings) are
 #undef TRY_C
 #undef HIP_C
@@ -3069,7 +2944,7 @@ static int ensure_frame(rt_ctx *ctx, uint64_t slots, int32_t sh) {
     // are the tile beams: without the memory for them levels share sets and run in sequence, pairs walk the tree themselves.
     // The estimate decides what is tried first; an allocation that fails all the same is tried again with less.
     int sets = 5;
-    bool tiles = !ctx->env.no_tiles;
+    bool tiles = true;
     auto set_bytes = [&](uint64_t c) {
         const uint64_t pairs = c * nsl1, rcap = rec_capacity(ctx, pairs, ctx->rec_div);
         return c * 40 + pairs * 8 + rcap * (16 * RT_PAIR_UNITS + 12) + (rcap / spb_keep + 2) * 8 * (RT_BLOCK / 64) + (uint64_t)((double)c * ctx->qgrowth) * 8;
@@ -3250,7 +3125,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                       std::max(ctx->cap, ctx->cap_deep) * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1) < (1ull << RT_LIST_NU_SHIFT);   // list entry: pair | units << 28
     // tile beams (level 0 of a camera frame in 8 x 8 tiles: the rays of a block of 64 slots are the pixels of a tile, their beams
     // towards a light nearly one beam); the binning buffers were carved for the frame sizes this context has seen
-    if (beam && cam && cam->tw * cam->th == 64 && (long long)cam->n_slots >= ctx->env.tiles_min && !lp.beam_early && !ctx->env.no_tiles && !(p->flags & RT_FLAG_NO_TILES) && ctx->beam.trec != nullptr) {
+    if (beam && cam && cam->tw * cam->th == 64 && (long long)cam->n_slots >= ctx->env.tiles_min && !lp.beam_early && !(p->flags & RT_FLAG_NO_TILES) && ctx->beam.trec != nullptr) {
         lp.tile_stride = (uint32_t)std::max(1, (cam->tiles_x + cam->world / 2) / std::max(cam->world, 1));
         const TileGrid G(cam->n_slots, lp.tile_stride);
         tiles = G.nblk <= ctx->tile_nblk && G.nreg <= ctx->tile_nreg && G.nzone <= ctx->tile_nzone;
@@ -3266,12 +3141,8 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
     // (ovl_main2) of a CU's 4 workgroup slots (amdgpu_waves_per_eu(4, 4), 256 threads each), the deeper levels ovl_side - together
     // never more than the slots there are, so that neither side ever waits for the other to retire (no kernel here spins on
     // another one's results, but a side that cannot get a slot runs after the other instead of beside it).
-    const bool slots_ok = ctx->env.ovl_main >= 1 && ctx->env.ovl_side >= 1 && ctx->env.ovl_main + ctx->env.ovl_side <= 4 &&
-                          ctx->env.ovl_main2 + ctx->env.ovl_side <= 6;      // (the per-ray kernels after the beam set-up use fewer registers: five of them and one 128-register workgroup fit a CU)
-    const bool overlap = fast && !prof && rec >= 1 && fb0 != ctx->fb && ctx->two_sets && !(p->flags & RT_FLAG_NO_OVERLAP) && ctx->n_cu >= 8 && slots_ok;
-    const int ovl_main = ctx->env.ovl_main;     // workgroups per CU, level-0 side
-    const int ovl_side = ctx->env.ovl_side;     // deeper levels
-    const int ovl_main2 = ctx->env.ovl_main2;   // level-0 kernels after the beam setup (side 3)
+    const bool overlap = fast && !prof && rec >= 1 && fb0 != ctx->fb && ctx->two_sets && !(p->flags & RT_FLAG_NO_OVERLAP) && ctx->n_cu >= 8;
+    const int ovl_main = RT_OVL_MAIN, ovl_side = RT_OVL_SIDE, ovl_main2 = RT_OVL_MAIN;      // (side 3: the level-0 kernels after the beam set-up; more of them per CU was measured: no gain)
     // grid of a kernel with nb workgroups per CU at full occupancy: side 0 = sequential, 1 = level-0 side, 2 = deeper levels
     auto gsz = [&](int full, int nb, int side) {
         if (!overlap || side == 0) return full;
@@ -3287,7 +3158,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
             {
                 // the kernel template that fits the scene: long beams or not, boxes or spheres only
                 const dim3 gs(gsz(ctx->g_beam_setup, ctx->nb_beam_setup, side));
-                const bool boxes = ctx->n_boxes > 0 || ctx->env.box_kernels;
+                const bool boxes = ctx->n_boxes > 0;
                 if (lp.tiles) {
                     // candidates per (block, light) by binning; small flat kernels in front of the pairs' own pass
                     // Small kernels of few registers: 8 workgroups per CU fit.  In an overlapped frame they keep to the level-0 side's
@@ -3295,7 +3166,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                     // them, and a CU full of binning workgroups makes that chain wait (measured, 3 against 8 per CU: 1920x1080
                     // 1.67 / 1.74 ms, half of 3840x2160 2.82 / 2.97, a quarter 1.57 / 1.61; the whole 3840x2160 frame, where the
                     // level-0 side is the long one, 5.45 / 5.38 - there they take the CUs).
-                    int bw = ctx->env.bin_wgs > 0 ? ctx->env.bin_wgs : ((overlap && side == 1 && ctx->fb_slots_frame <= (4u << 20)) ? ovl_main : 8);
+                    const int bw = (overlap && side == 1 && ctx->fb_slots_frame <= (4u << 20)) ? ovl_main : 8;
                     const dim3 gt((ctx->n_cu * bw + 7) & ~7);
                     if (!gen) hipLaunchKernelGGL(k_block_box, gt, block, 0, s_, ctx->S, lp, hb, bb, ctx->ctl);      // (else: k_intersect<.., true> wrote the boxes)
                     hipLaunchKernelGGL(k_bin_zone, gt, block, 0, s_, ctx->S, ctx->F, lp, bb, ctx->ctl);
@@ -3345,8 +3216,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
             }
             if (fast) hipLaunchKernelGGL((k_intersect<true, true>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side_)), block, ctx->lds_bytes + ctx->lds_top_bytes, s_, ctx->S, ctx->F, lp, qc, qn, hb, ctx->ctl, fbx, ids, *gen, bc, side, side2, to);
             else hipLaunchKernelGGL((k_intersect<false, true>), dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, qn, hb, ctx->ctl, fbx, ids, *gen, bc, side, side2, to);
-        } else if (fast && ctx->F.inv_seg_len > 0.0f) hipLaunchKernelGGL((k_intersect<true, false, true>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side_)), block, ctx->lds_bytes + ctx->lds_top_bytes, s_, ctx->S, ctx->F, lp, qc, qn, hb, ctx->ctl, fbx, ids, none, bc, nullptr, nullptr, to);
-        else if (fast) hipLaunchKernelGGL((k_intersect<true, false>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side_)), block, ctx->lds_bytes + ctx->lds_top_bytes, s_, ctx->S, ctx->F, lp, qc, qn, hb, ctx->ctl, fbx, ids, none, bc, nullptr, nullptr, to);
+        } else if (fast) hipLaunchKernelGGL((k_intersect<true, false>), dim3(gsz(ctx->g_intersect, ctx->nb_intersect, side_)), block, ctx->lds_bytes + ctx->lds_top_bytes, s_, ctx->S, ctx->F, lp, qc, qn, hb, ctx->ctl, fbx, ids, none, bc, nullptr, nullptr, to);
         else hipLaunchKernelGGL((k_intersect<false, false>), dim3(ctx->g_intersect_x), block, 0, s_, ctx->S, ctx->F, lp, qc, qn, hb, ctx->ctl, fbx, ids, none, bc, nullptr, nullptr, to);
     };
     auto queue_of = [&](int level) -> RayQ & { return level == 0 ? ctx->q[0] : ctx->q[1 + ((level - 1) & 1)]; };
@@ -3400,7 +3270,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                            ctx->beam.litbits, ctx->beam.pair_slot, ctx->beam.queue_n);
         // deeper levels (stream2): few, long rays - their waves ask for issue priority over the level-0 waves
         // (in frames of many million pixels the level-0 side is the long one and the priority only slows it down)
-        lp.prio = ctx->env.no_prio ? 0 : (ctx->env.prio || ctx->fb_slots_frame <= (4u << 20) ? 1 : 0);
+        lp.prio = ctx->fb_slots_frame <= (4u << 20) ? 1 : 0;
         const bool no_pipe = ctx->env.no_pipeline;
         if (ctx->three_sets && rec >= 2 && !no_pipe) {
             // Soft shadows of consecutive levels run side by side (odd levels on stream3, even levels on stream4: each is a latency
@@ -3434,7 +3304,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                 if (level > nd) HIP_TRY(ctx, hipStreamWaitEvent(s2_, ctx->ev_lit[level - nd], 0));
                 intersect(level, s2_, qc, qn, hb, fbm, 2, bb);       // (+ the children: the next link of the frame's critical chain needs nothing else)
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_hit[level], s2_));
-                hipStream_t s3_ = (odd || ctx->env.one_shadow_stream) ? ctx->stream3 : s4_;
+                hipStream_t s3_ = odd ? ctx->stream3 : s4_;
                 HIP_TRY(ctx, hipStreamWaitEvent(s3_, ctx->ev_hit[level], 0));
                 if (int rc = shadows(level, s3_, qc, hb, bb, 2)) return rc;
                 if (level >= 2) HIP_TRY(ctx, hipStreamWaitEvent(s3_, ctx->ev_lit[level - 1], 0));
@@ -3476,6 +3346,7 @@ static GenParams gen_params(const rt_ctx *ctx, const TileGeom &g) {
     }
     gp.W = g.W; gp.H = g.H; gp.tiles_x = g.tiles_x; gp.n_tiles = g.n_tiles; gp.rank = g.rank; gp.world = g.world;
     gp.tw = g.tw; gp.th = g.th; gp.n_slots = (uint32_t)g.slots;
+    gp.rcp_tiles_x = 1.0f / (float)g.tiles_x;
     return gp;
 }
 
@@ -3635,6 +3506,7 @@ extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
         for (int l = 0; l <= ctx->last_rec && l < RT_MAX_LEVELS; ++l)
             fprintf(stderr, "[rt_amd] level %d: %llu pairs, %u listed, %u rays of overflowing pairs, %u rays queued by the filters\n", l,
                     (unsigned long long)c.n_hits[l] * (unsigned long long)ctx->S.n_shadow_lights, c.n_listed[l], c.n_walked[l], c.n_queued[l]);
+#ifdef RT_DIAG
         fprintf(stderr, "[rt_amd] beam traversal trips (flag 0x1000): max %u, total %llu; pairs to the queue: delicate %u, touched %u, units %u, dedup %u\n",
                 c.dbg_max_trips, c.dbg_sum_trips, c.dbg_why[0], c.dbg_why[1], c.dbg_why[2], c.dbg_why[3]);
         if (c.dbg_tile[2])
@@ -3643,6 +3515,7 @@ extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
         if (c.dbg_tcyc[3])
             fprintf(stderr, "[rt_amd] tile beams: longest zone list %u; clocks of thread 0 over all rows: set-up %llu, region filter %llu, block filter %llu; longest row %llu\n",
                     c.dbg_tile[0], c.dbg_tcyc[0], c.dbg_tcyc[1], c.dbg_tcyc[2], c.dbg_tcyc[3]);
+#endif
         // candidate units of the listed pairs of the LAST level (render with rec_max = 0 to see level 0)
         uint32_t qn[4] = {0, 0, 0, 0};
         (void)hipMemcpy(qn, ctx->beam.queue_n, sizeof(qn), hipMemcpyDeviceToHost);
@@ -3860,7 +3733,7 @@ extern "C" int rt_intersect_device(rt_ctx *ctx, const double *d_origins, const d
     if (n == 0) return RT_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    if (ctx->F.ok && !ctx->env.exact)
+    if (ctx->F.ok)
         hipLaunchKernelGGL(k_intersect_only<true>, dim3(ctx->grid), dim3(RT_BLOCK), ctx->lds_bytes, st, ctx->S, ctx->F, d_origins, d_directions, (uint64_t)n, d_points_out, d_ids_out);
     else
         hipLaunchKernelGGL(k_intersect_only<false>, dim3(ctx->grid), dim3(RT_BLOCK), 0, st, ctx->S, ctx->F, d_origins, d_directions, (uint64_t)n, d_points_out, d_ids_out);
@@ -3896,7 +3769,7 @@ extern "C" int rt_visibility_device(rt_ctx *ctx, const double *d_origins, const 
     if (n == 0) return RT_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    if (ctx->F.ok && !ctx->env.exact)
+    if (ctx->F.ok)
         hipLaunchKernelGGL(k_visibility<true>, dim3(ctx->grid), dim3(RT_BLOCK), ctx->lds_bytes, st, ctx->S, ctx->F, d_origins, d_directions, d_targets, (uint64_t)n, d_lit_out);
     else
         hipLaunchKernelGGL(k_visibility<false>, dim3(ctx->grid), dim3(RT_BLOCK), 0, st, ctx->S, ctx->F, d_origins, d_directions, d_targets, (uint64_t)n, d_lit_out);
@@ -4058,6 +3931,7 @@ extern "C" int rt_initial_rays(rt_ctx *ctx, int width, int height, double *sourc
     }
     gp.W = g.W; gp.H = g.H; gp.tiles_x = g.tiles_x; gp.n_tiles = g.n_tiles; gp.rank = 0; gp.world = 1;
     gp.tw = g.tw; gp.th = g.th; gp.n_slots = (uint32_t)g.slots;
+    gp.rcp_tiles_x = 1.0f / (float)g.tiles_x;
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipMemsetAsync(ctx->ctl, 0, sizeof(FrameCtl), st));
     hipLaunchKernelGGL(k_gen, dim3(ctx->grid), dim3(RT_BLOCK), 0, st, gp, ctx->q[0], ctx->ctl);

@@ -217,9 +217,16 @@ __device__ __forceinline__ d3 jitter3(uint32_t seed, uint32_t pixel, uint32_t pa
     return mk3(-g + (2 * g) * ((double)x * k), -g + (2 * g) * ((double)y * k), -g + (2 * g) * ((double)z * k));
 }
 
-// path code of a child ray (jitter hash key): root 1, through 2k, mirror 2k + 1 - must stay identical to child_path() in
-// oracle/oracle.cpp
-__device__ __forceinline__ uint32_t child_path(uint32_t path, uint32_t mirror) { return path * 2u + mirror; }
+// Path code of a child ray (a key of the jitter hash): root 1, through 2k, mirror 2k + 1 - the path's turns as a bit string
+// under a leading 1 - down to recursion level 31.  Deeper, the string no longer fits 32 bits (shifting on would drop the leading
+// turns, and different paths of one pixel would draw the same deviations): from there the code is a hash of (parent code, turn),
+// kept above 2^31 so that it cannot meet a shallow code.  Must stay identical to child_path() in oracle/oracle.cpp.
+__device__ __forceinline__ uint32_t child_path(uint32_t path, uint32_t mirror) {
+    if (path < 0x80000000u) return path * 2u + mirror;
+    uint32_t h = (path ^ (mirror * 0x85EBCA6Bu + 0x9E3779B1u)) * 0x2C1B3C6Du;
+    h ^= h >> 15; h *= 0x297A2D39u; h ^= h >> 15;
+    return h | 0x80000000u;
+}
 
 // util.get_orthonormal_vector (util.py:113-132) + create_orthonormal_basis (util.py:65-75)
 __device__ __forceinline__ void light_basis(d3 D, d3 &up, d3 &right) {

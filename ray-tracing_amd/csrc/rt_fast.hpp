@@ -51,7 +51,6 @@ struct FastScene {
     // every cut location and root bound of the tree, per axis, rounded to float32, sorted, distinct (on_node_plane)
     const float *cuts[3];
     int32_t n_cuts[3];
-    float inv_seg_len;              // 1 / length of the pieces k_intersect cuts long rays into (0: never cut)
     // the internal nodes of the first levels once more, breadth first, 16 bytes each {cut bits, axis, left ref, right ref}: the
     // nearest-hit kernels copy this table into LDS (rt_top_stage) and take the first steps of every descent from there - a
     // step is a dependent load, ~1 us from L2 / Infinity Cache against ~0.1 us from LDS, and most steps of a short ray are

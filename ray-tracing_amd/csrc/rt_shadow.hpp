@@ -22,6 +22,11 @@
 #include <hip/hip_fp16.h>
 #include "rt_fast.hpp"
 
+#ifdef RT_DIAG
+#define RT_DIAG_ONLY(x) x
+#else
+#define RT_DIAG_ONLY(x)
+#endif
 #define RT_CUNITS 12         // 16-byte candidate units kept per (hit, light) pair: a sphere takes 1, a box 2
 #define RT_CMAX RT_CUNITS
 #define RT_TOUCH 8          // leaf entries a pair's traversal may park before its rays go to the float64 queue
@@ -337,7 +342,6 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
                 cnt = T->tcnt[cur];
             }
             cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
-            if (dbg & 0x10000) cnt = 0u;                 // timing experiment only
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // earlier reads of the slice are done (WAR)
             __builtin_amdgcn_wave_barrier();
             (T->lane < (int)RT_TILE_HALF ? T->rowbuf : T->rowbuf_hi)[T->lane] = part;
@@ -400,7 +404,7 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
         KNode nd = F.knodes[node];
         while ((nd.b & 3u) != 3u) {
             const uint32_t ax = nd.b & 3u;
-            ++R.trips;
+            RT_DIAG_ONLY(++R.trips;)
             const float cut = __uint_as_float(nd.a) - sel3(ax, Pf0, Pf1, Pf2);
             const float La = sel3(ax, L0, L1, L2), Ua = sel3(ax, U0, U1, U2), iLa = sel3(ax, iL0, iL1, iL2), iUa = sel3(ax, iU0, iU1, iU2);
             float a0 = l0, a1 = l1, b0 = l0, b1 = l1;
@@ -431,7 +435,7 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
             const float blo2 = fminf(m0 * L2, m1 * L2) - E, bhi2 = fmaxf(m0 * U2, m1 * U2) + E;
             // one leaf entry against the beam's part in this leaf; true: a sphere hides the whole light (EARLY), R is final
             auto entry = [&](const LeafF &lf) -> bool {
-                ++R.trips;
+                RT_DIAG_ONLY(++R.trips;)
                 const bool sph = !BOXES || (lf.pk & 3u) == 1u;     // sphere {centre, r, (low parts)}; box {lo, -, hi}
                 const float rr = sph ? lf.r : 0.0f;
                 const float c0 = lf.x - Pf0, c1 = lf.y - Pf1, c2 = lf.z - Pf2;
@@ -514,7 +518,7 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
         if (!live) return R;
         if (wide) { R.overflow = true; R.why = 1; return R; }
     }
-    if (nt > RT_TOUCH || ntu > RT_CUNITS + 4u || (dbg & 0x2000)) { R.overflow = true; R.why = 1; return R; }
+    if (nt > RT_TOUCH || ntu > RT_CUNITS + 4u) { R.overflow = true; R.why = 1; return R; }
 
     // ---- phase 2: the touched primitives.  Whole-pair verdicts, float64 re-expression.
     uint32_t nu = 0, boxmask = 0;                    // units used, which units start a box

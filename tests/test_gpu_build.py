@@ -189,3 +189,18 @@ def test_main_writes_the_same_image_with_either_ingestion(tmp_path):
     ray_tracer.main([common[0], b] + common[2:] + ["--python-ingest"])
     ia, ib = np.asarray(Image.open(a)), np.asarray(Image.open(b))
     assert ia.shape == (54, 96, 3) and np.array_equal(ia, ib) and ia.max() > 0
+
+
+def test_a_tree_that_blows_up_is_refused_not_built():
+    """more than ten objects through one point make the reference's builder copy them into both children level
+    after level until the cells fall below EPSILON - 2^60 references for twelve unit cubes on one spot (the reference dies
+    of it too).  rt_bsp_build stops when a level would exceed 2^30 references and says so: RT_ERR_UNSUPPORTED with a
+    message, no crash, no endless build; the next call works."""
+    n = 12
+    lo, hi = np.full((n, 3), -0.5), np.full((n, 3), 0.5)
+    with pytest.raises(native.NativeError) as e:
+        native.bsp_build(lo, hi)
+    assert e.value.code == abi.RT_ERR_UNSUPPORTED
+    assert "2^30" in str(e.value)
+    t = native.bsp_build(lo[:10], hi[:10])          # ten of them: one leaf (BSPNode.py:67)
+    assert len(t["right"]) == 1 and t["count"][0] == 10

@@ -602,3 +602,36 @@ def test_random_scene_files_render_like_the_oracle(oracle, seed, tmp_path):
     assert np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
     for key in ("primary_rays", "shadow_rays", "reflect_rays", "transmit_rays", "hits"):
         assert out["stats"][key] == ref["counters"][key], key
+
+
+def test_path_codes_beyond_recursion_level_31(oracle, tmp_path):
+    """The jitter hash is keyed by the ray's path code, whose bit string fills 32 bits at recursion level 31 (rt_device.hpp,
+    child_path): a mirror floor under a mirror ceiling carries rays through all 41 levels of rec_max = 40; past level 31 the code
+    is a hash chain.
+    GPU frame == oracle frame with the hashed jitter on (ids, 8-bit colours, every ray counter), and the deep levels are
+    really reached."""
+    from ray_tracing_amd.render import Scene
+    text = "\n".join([
+        "cam 0 0.5 -6   0 0.45 0   0 1 0   1.0 1.0",
+        "set 0.2 0.3 0.4  3 40",
+        "mtl 0.1 0.1 0.1  0.3 0.3 0.3  0.95 0.95 0.95  20 0",      # mirrors
+        "mtl 0.6 0.2 0.2  0.5 0.5 0.5  0 0 0  8 0",
+        "pln 0 1 0  -0.5  1",                                         # a mirror floor ...
+        "pln 0 -1 0  -1.5  1",                                        # ... under a mirror ceiling (planes are one-sided: each faces the other)
+        "sph 0 0.5 0  0.6  1",
+        "sph 1.6 0.0 -1.0  0.5  2",
+        "lgt 3 1.2 -4   1 1 1   1 0.8 0.5",
+        "lgt -4 1.0 -3  0.8 0.8 1  1 0.6 0.4",
+    ]) + "\n"
+    p = tmp_path / "mirrors.txt"
+    p.write_text(text)
+    sc = Scene.from_file(str(p))
+    prm = abi.render_params(48, 32, jitter=True, seed=9)
+    ref = oracle.render(sc.packed, prm)
+    with native.Context(sc.packed, device=0) as ctx:
+        out = ctx.render(prm)
+    assert out["stats"]["levels"] >= 35, out["stats"]["levels"]
+    assert np.array_equal(out["ids"], ref["ids"])
+    assert np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
+    for key in ("primary_rays", "shadow_rays", "reflect_rays", "transmit_rays", "hits"):
+        assert out["stats"][key] == ref["counters"][key], key

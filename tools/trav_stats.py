@@ -40,11 +40,10 @@ def main():
         if hasattr(lib, "rt_debug_trav_time"):
             rc = lib.rt_debug_trav_time(buf, 8 * 64)
             assert rc == 0
-            print("level: us (max over waves) planes+root | first pieces | further pieces ; pieces dealt, max rounds, exact walks ; kernel us")
+            print("level: longest wave of k_intersect, us")
             for l in range(12):
-                if not any(buf[8 * l + k] for k in range(8)):
-                    continue
-                print(l, *["%.1f" % (buf[8 * l + k] / 100.0) for k in range(3)], ";", buf[8 * l + 4], buf[8 * l + 5], buf[8 * l + 6], "; %.1f" % (buf[8 * l + 7] / 100.0))
+                if buf[8 * l + 7]:
+                    print(l, "%.1f" % (buf[8 * l + 7] / 100.0))
 
 
 if __name__ == "__main__":
