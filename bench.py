@@ -16,7 +16,7 @@ reference counts them (every ray given to BSPNode.intersect_vectorize), whole jo
 
 Rank 0 prints ONE JSON line.  `roofline` is about the frame's dominant kernel, k_beam_setup: its launches are timed live
 with HIP events on their stream (profile frames after the timed loop), and the floating-point work it EXECUTES per frame
-(hardware counters of this very workload and tree, profiles/r02_pmc_<workload>.json, made by tools/pmc_roofline.sh) is
+(hardware counters of this very workload and tree, profiles/r03_pmc_<workload>.json, made by tools/pmc_roofline.sh) is
 divided by that time: a fraction of the FP32 vector peak that cannot exceed 1.  The rate of the REFERENCE's algorithmic
 work is printed beside it under its own name - the pipeline skips most of that work (whole-pair
 verdicts), so it is no statement about the hardware.  `cpu_baseline`: the float64 oracle on a bounded sub-sampled frame,
@@ -91,10 +91,11 @@ def profile_file(workload, W, H, world):
     collected on the 1920x1080 frame; for another shape of the same scene (a rank's share of 3840x2160) the executed work is
     scaled by the number of (hit, light) pairs, which is what the kernel's work is proportional to (same scene, same camera)."""
     name = {"synth10k": "synth10k_1920x1080"}.get(workload)
-    path = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % name) if name else None
-    if path and os.path.exists(path):
-        with open(path) as f:
-            return json.load(f), os.path.relpath(path, ROOT), PMC_FRAME_HITS[name]
+    for rnd in ("r03", "r02"):             # the newest round's counters (same kernels, same tree as this library)
+        path = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, name)) if name else None
+        if path and os.path.exists(path):
+            with open(path) as f:
+                return json.load(f), os.path.relpath(path, ROOT), PMC_FRAME_HITS[name]
     return None, None, None
 
 
@@ -398,7 +399,17 @@ def main():
             with native.Context(pool.packed, device=gpu_index) as pctx:
                 p1 = time_frames(pctx, abi, native, torch, stream, 1920, 1080, 60, 10, sh_rays=1, jitter=False)
                 p5 = time_frames(pctx, abi, native, torch, stream, 1920, 1080, 60, 10, sh_rays=5, jitter=True)
+            # the reference's own default scene and output size (ray_tracer.py: scenes/original.txt, 500x500), and the largest
+            # scene of BASELINE's size ladder (10^6 spheres)
+            orig, _ = build_scene("original", args.ingest, gpu_index)
+            with native.Context(orig.packed, device=gpu_index) as octx:
+                po = time_frames(octx, abi, native, torch, stream, 500, 500, 60, 10, jitter=True)
+            big, _ = build_scene("synth1M", args.ingest, gpu_index)
+            with native.Context(big.packed, device=gpu_index) as bctx:
+                pb = time_frames(bctx, abi, native, torch, stream, 1920, 1080, 20, 5, jitter=True)
+            del orig, big
             extra = {"pool_1920x1080_s1_nojitter_ms": round(p1, 3), "pool_1920x1080_s5_ms": round(p5, 3),
+                     "original_500x500_ms": round(po, 3), "synth1M_1920x1080_ms": round(pb, 3),
                      "reference_numpy_pool_1920x1080_s1_s": 37.3, "speedup_vs_reference_s1": round(37.3e3 / p1, 0),
                      "note": "device-side frame time (HIP events around 60 frames after 10); reference time from BASELINE.md (build container, 1 core)"}
 

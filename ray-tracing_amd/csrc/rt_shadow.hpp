@@ -215,6 +215,16 @@ __device__ __forceinline__ void clip_mul(float &l0, float &l1, float coef, float
     l1 = (coef == 0.0f && rhs < 0.0f) ? -1.0f : l1;  // 0 <= rhs fails: empty
 }
 
+// A primitive's box [c - rr, d + rr] (sphere: c = d = centre, rr = radius; box: c = lo, d = hi, rr = 0) lies apart from the box
+// [blo, bhi] on some axis.  One maximum over the six signed gaps instead of six compares ANDed together (x > y <=> x - y > 0;
+// a NaN gap is dropped by the maximum as it was by its compare: never a reason to cull).
+__device__ __forceinline__ bool boxes_apart(float c0, float c1, float c2, float d0, float d1, float d2, float rr, float blo0, float blo1, float blo2,
+                                            float bhi0, float bhi1, float bhi2) {
+    const float g0 = (c0 - rr) - bhi0, g1 = (c1 - rr) - bhi1, g2 = (c2 - rr) - bhi2;
+    const float h0 = blo0 - (d0 + rr), h1 = blo1 - (d1 + rr), h2 = blo2 - (d2 + rr);
+    return fmaxf(fmaxf(fmaxf(g0, g1), g2), fmaxf(fmaxf(h0, h1), h2)) > 0.0f;
+}
+
 // Stack entry of the beam traversal: (node, lambda interval as two float16, rounded outward by up to 1.5 ulp).
 // 8 bytes per level and lane, like the stacks of rt_fast.hpp; lambda is in [0, 1], 2^-11 relative is ~0.01
 // length units at the far end of a beam.
@@ -369,8 +379,7 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
                     const float rr = sph ? ra.w : 0.0f;
                     const float c0 = ra.x - Pf0, c1 = ra.y - Pf1, c2 = ra.z - Pf2;
                     const float d0 = sph ? c0 : rb4.x - Pf0, d1 = sph ? c1 : rb4.y - Pf1, d2 = sph ? c2 : rb4.z - Pf2;
-                    bool keep = mine && !(c0 - rr > bhi0) && !(d0 + rr < blo0) && !(c1 - rr > bhi1) && !(d1 + rr < blo1) &&
-                                !(c2 - rr > bhi2) && !(d2 + rr < blo2);
+                    bool keep = mine && !boxes_apart(c0, c1, c2, d0, d1, d2, rr, blo0, blo1, blo2, bhi0, bhi1, bhi2);
                     if (cone_ok) {                           // as in the walk's leaf loop
                         const float m0_ = sph ? c0 : 0.5f * (c0 + d0), m1_ = sph ? c1 : 0.5f * (c1 + d1), m2_ = sph ? c2 : 0.5f * (c2 + d2);
                         const float e0_ = d0 - c0, e1_ = d1 - c1, e2_ = d2 - c2;
@@ -440,8 +449,7 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
                 const float rr = sph ? lf.r : 0.0f;
                 const float c0 = lf.x - Pf0, c1 = lf.y - Pf1, c2 = lf.z - Pf2;
                 const float d0 = sph ? c0 : lf.lx - Pf0, d1 = sph ? c1 : lf.ly - Pf1, d2 = sph ? c2 : lf.lz - Pf2;
-                const bool touch = !(c0 - rr > bhi0) && !(d0 + rr < blo0) && !(c1 - rr > bhi1) && !(d1 + rr < blo1) &&
-                                   !(c2 - rr > bhi2) && !(d2 + rr < blo2);
+                const bool touch = !boxes_apart(c0, c1, c2, d0, d1, d2, rr, blo0, blo1, blo2, bhi0, bhi1, bhi2);
                 if (touch) {
                     bool in_cone = true;
                     if (cone_ok) {
@@ -729,8 +737,7 @@ __device__ __forceinline__ int ray_walk(const DScene &S, const FastScene &F, uin
                     const float rr = sph ? lf.r : 0.0f;
                     const float c0 = lf.x - Pf0, c1 = lf.y - Pf1, c2 = lf.z - Pf2;
                     const float d0 = sph ? c0 : lf.lx - Pf0, d1 = sph ? c1 : lf.ly - Pf1, d2 = sph ? c2 : lf.lz - Pf2;
-                    bool touch = !(c0 - rr > bhi0) && !(d0 + rr < blo0) && !(c1 - rr > bhi1) && !(d1 + rr < blo1) &&
-                                 !(c2 - rr > bhi2) && !(d2 + rr < blo2);
+                    bool touch = !boxes_apart(c0, c1, c2, d0, d1, d2, rr, blo0, blo1, blo2, bhi0, bhi1, bhi2);
                     // bounding sphere against the thin cone (same test as the beam's, beam_collect)
                     const float m0_ = sph ? c0 : 0.5f * (c0 + d0), m1_ = sph ? c1 : 0.5f * (c1 + d1), m2_ = sph ? c2 : 0.5f * (c2 + d2);
                     const float e0_ = d0 - c0, e1_ = d1 - c1, e2_ = d2 - c2;
