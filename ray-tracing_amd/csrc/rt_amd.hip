@@ -3553,6 +3553,16 @@ extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
         else ctx->growth *= 2.0;
         return fail(ctx, RT_ERR_QUEUE_OVERFLOW, "secondary-ray queue overflow; queue growth factor doubled, render again");
     }
+    // Pair records close to running out (frames of one scene differ by a few percent from seed to seed): give the next frames
+    // room now, at this synchronisation point, rather than void one of them later in a loop that does not synchronise.
+    if (!ctx->last_noalloc && ctx->rec_div_carved > 1.0 && ctx->rec_div >= ctx->rec_div_carved) {
+        double worst = 0.0;
+        for (int l = 0; l <= ctx->last_rec && l < RT_MAX_LEVELS; ++l) {
+            const BeamBuf &bb = *beam_set(*ctx, (l == 0 || !ctx->two_sets) ? 0 : 1);
+            if (bb.rec_cap) worst = std::max(worst, (double)c.n_listed[l] / (double)bb.rec_cap);
+        }
+        if (worst > 0.8) ctx->rec_div = std::max(1.0, ctx->rec_div_carved * 0.6 / worst);
+    }
     return RT_OK;
 }
 

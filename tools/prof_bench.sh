@@ -1,11 +1,13 @@
 #!/bin/bash
-# usage: tools/prof_bench.sh <tag>  - the default bench line, then rocprofv3 --kernel-trace --stats of the same command
+# usage: tools/prof_bench.sh <tag>  - the default bench line, then rocprofv3 --kernel-trace --stats of the same workload
+# (bench.py --no-cpu-baseline --no-extra: without the CPU sample and without the other scenes' frames of extra_frames, so that
+# the per-kernel averages are those of the headline frame alone)
 tag=$1
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/$tag
 timeout -k 10 400 python bench.py > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err || { echo "bench failed"; tail -5 gpurun_out/$tag/bench.err; exit 1; }
 cat gpurun_out/$tag/bench.json
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag/prof -- python bench.py --no-cpu-baseline > gpurun_out/$tag/bench_prof.json 2> gpurun_out/$tag/prof.err || { echo "rocprof failed"; tail -5 gpurun_out/$tag/prof.err; exit 1; }
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag/prof -- python bench.py --no-cpu-baseline --no-extra > gpurun_out/$tag/bench_prof.json 2> gpurun_out/$tag/prof.err || { echo "rocprof failed"; tail -5 gpurun_out/$tag/prof.err; exit 1; }
 cat gpurun_out/$tag/bench_prof.json
 python - "$tag" <<'PY'
 import csv, glob, sys
