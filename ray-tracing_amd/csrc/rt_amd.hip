@@ -71,6 +71,7 @@ struct FrameCtl {
     unsigned long long dbg_tcyc[4];
     uint32_t dbg_tile[8];                   // flag 0x1000, tile beams: (zone, light) rows / entries, (region, light) rows / entries / overflows, (block, light) rows / entries / overflows
     unsigned long long dbg_sum_trips;
+    unsigned long long dbg_bcyc[8];         // flag 0x4000, k_beam_setup, clocks of lane 0 of every wave: pair set-up, tile rows, tree walk, touched primitives, verdict + record, trips
 };
 
 struct RayQ {            // SoA ray queue in HBM
@@ -1054,7 +1055,9 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
     ChunkWalk walk((uint64_t)hit_blocks * nsl * 64u);
     uint64_t first;
     (void)total;
+    RT_DIAG_ONLY(unsigned long long bsum0 = 0, bsum1 = 0, bsum2 = 0, bsum3 = 0, bsum4 = 0, bsum5 = 0;)
     while (walk.next(first)) {
+        RT_DIAG_ONLY(const unsigned long long bc0 = clock64(); unsigned long long bc1 = bc0, bc2 = bc0, bc3 = bc0, bc4 = bc0;)
         const uint32_t wg = (uint32_t)(first >> 6) + (threadIdx.x >> 6);     // (hit block, light)
         const uint32_t hblk = wg / nsl, ml = wg - hblk * nsl;
         const uint32_t h = (hblk << 6) + (uint32_t)lane;
@@ -1143,6 +1146,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                     n_atp += c == RT_PLANE_ATP;
                 }
             BeamOut bo;
+            RT_DIAG_ONLY(bc1 = clock64(); bo.clk_rows = bo.clk_walk = bc1;)
             bo.nu = 0; bo.boxmask = 0; bo.keep = 0; bo.overflow = true; bo.occ_all = false; bo.atp_all = false; bo.trips = 0; bo.why = 0;
             if (!delicate || TILES) {
                 {
@@ -1177,6 +1181,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                 if (bo.overflow) atomicAdd(&ctl->dbg_why[delicate ? 0 : bo.why], 1u);
             }
 #endif
+            RT_DIAG_ONLY(bc2 = bo.clk_rows; bc3 = bo.clk_walk; bc4 = clock64();)
             // every |sample - P| inside the per-ray filter's range (k_shadow_beam: 1e-4 < nv < 1e7)
             const float sc = __builtin_amdgcn_sqrtf(fmaf(cB0, cB0, fmaf(cB1, cB1, cB2 * cB2))), sh = __builtin_amdgcn_sqrtf(fmaf(h0, h0, fmaf(h1, h1, h2 * h2)));
             const bool range_ok = sc - sh > 1.1e-3f && sc + sh < 0.9e6f;
@@ -1247,7 +1252,19 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
             }
         }
         wave_append(ovf, (unsigned long long)seg | ((unsigned long long)slot << 32), obuf, on, &bb.queue_n[2], lane, store_ovf);
+#ifdef RT_DIAG
+        {
+            const unsigned long long bc5 = clock64();
+            bsum0 += bc1 - bc0; bsum1 += bc2 - bc1; bsum2 += bc3 - bc2; bsum3 += bc4 - bc3; bsum4 += bc5 - bc4; ++bsum5;
+        }
+#endif
     }
+#ifdef RT_DIAG
+    if ((lp.flags & 0x4000) && lane == 0) {
+        atomicAdd(&ctl->dbg_bcyc[0], bsum0); atomicAdd(&ctl->dbg_bcyc[1], bsum1); atomicAdd(&ctl->dbg_bcyc[2], bsum2);
+        atomicAdd(&ctl->dbg_bcyc[3], bsum3); atomicAdd(&ctl->dbg_bcyc[4], bsum4); atomicAdd(&ctl->dbg_bcyc[5], bsum5);
+    }
+#endif
     // the unused tail of the wave's last block: no pair there
     if ((uint32_t)lane < blk_left) bb.list[blk_end - blk_left + (uint32_t)lane] = RT_LIST_NONE;
     wave_append_flush(obuf, on, &bb.queue_n[2], lane, store_ovf);
@@ -3512,6 +3529,10 @@ extern "C" int rt_sync_stats(rt_ctx *ctx, rt_stats *stats) {
         if (c.dbg_tile[2])
             fprintf(stderr, "[rt_amd] tile beams (flag 0x1000): %u (region, light) rows scanned %u zone-list entries and kept %u (%u overflowing); %u (block, light) rows list %u candidates (%u overflowing)\n",
                     c.dbg_tile[2], c.dbg_tile[1], c.dbg_tile[3], c.dbg_tile[4], c.dbg_tile[5], c.dbg_tile[6], c.dbg_tile[7]);
+        if (c.dbg_bcyc[5])
+            fprintf(stderr, "[rt_amd] k_beam_setup, all levels, clocks per (64 hits, light) trip of a wave (flag 0x4000, %llu trips): pair set-up %.0f, tile rows %.0f, tree walk %.0f, touched primitives %.0f, verdict + record %.0f\n",
+                    c.dbg_bcyc[5], (double)c.dbg_bcyc[0] / c.dbg_bcyc[5], (double)c.dbg_bcyc[1] / c.dbg_bcyc[5], (double)c.dbg_bcyc[2] / c.dbg_bcyc[5],
+                    (double)c.dbg_bcyc[3] / c.dbg_bcyc[5], (double)c.dbg_bcyc[4] / c.dbg_bcyc[5]);
         if (c.dbg_tcyc[3])
             fprintf(stderr, "[rt_amd] tile beams: longest zone list %u; clocks of thread 0 over all rows: set-up %llu, region filter %llu, block filter %llu; longest row %llu\n",
                     c.dbg_tile[0], c.dbg_tcyc[0], c.dbg_tcyc[1], c.dbg_tcyc[2], c.dbg_tcyc[3]);

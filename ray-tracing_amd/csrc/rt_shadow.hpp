@@ -23,9 +23,9 @@
 #include "rt_fast.hpp"
 
 #ifdef RT_DIAG
-#define RT_DIAG_ONLY(x) x
+#define RT_DIAG_ONLY(...) __VA_ARGS__
 #else
-#define RT_DIAG_ONLY(x)
+#define RT_DIAG_ONLY(...)
 #endif
 #define RT_CUNITS 12         // 16-byte candidate units kept per (hit, light) pair: a sphere takes 1, a box 2
 #define RT_CMAX RT_CUNITS
@@ -257,6 +257,9 @@ struct BeamOut {
     bool atp_all;            // P lies on a sphere that every ray of the pair leaves through P (not stored in out[])
     uint32_t trips;          // diagnostics: node steps + leaf entries looked at
     uint32_t why;            // diagnostics: 1 touched list full, 2 candidate units full, 3 dedup list full
+#ifdef RT_DIAG
+    unsigned long long clk_rows, clk_walk;     // clock at the end of the tile rows / of the tree walk (make stats)
+#endif
 };
 
 // c* / h*: centre and half size of the box of all sample origins, relative to P.  The candidates' units are NOT written here:
@@ -296,12 +299,17 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
                                                 bool on = true, const TileRow *T = nullptr) {
     BeamOut R;
     R.nu = 0; R.boxmask = 0; R.keep = 0; R.overflow = false; R.occ_all = false; R.atp_all = false; R.trips = 0; R.why = 0;
+    RT_DIAG_ONLY(R.clk_rows = R.clk_walk = clock64();)
     const float Pf0 = (float)P.x, Pf1 = (float)P.y, Pf2 = (float)P.z;
     const float Kp = fmaxf(fmaxf(fabsf(Pf0), fabsf(Pf1)), fmaxf(fabsf(Pf2), F.extent));
     const float E = Kp * RT_2M19 + 2e-6f;            // absolute slack on every plane position (and the 1e-6 offsets)
     const float L0 = cB0 - h0, L1 = cB1 - h1, L2 = cB2 - h2, U0 = cB0 + h0, U1 = cB1 + h1, U2 = cB2 + h2;
-    const float iL0 = __builtin_amdgcn_rcpf(L0), iL1 = __builtin_amdgcn_rcpf(L1), iL2 = __builtin_amdgcn_rcpf(L2);
-    const float iU0 = __builtin_amdgcn_rcpf(U0), iU1 = __builtin_amdgcn_rcpf(U1), iU2 = __builtin_amdgcn_rcpf(U2);
+    // (tile beams: the reciprocals and the root-box clip belong to the tree walk, which few pairs need - computed there)
+    float iL0 = 0.0f, iL1 = 0.0f, iL2 = 0.0f, iU0 = 0.0f, iU1 = 0.0f, iU2 = 0.0f;
+    if (!TILES) {
+        iL0 = __builtin_amdgcn_rcpf(L0); iL1 = __builtin_amdgcn_rcpf(L1); iL2 = __builtin_amdgcn_rcpf(L2);
+        iU0 = __builtin_amdgcn_rcpf(U0); iU1 = __builtin_amdgcn_rcpf(U1); iU2 = __builtin_amdgcn_rcpf(U2);
+    }
     // the beam also lies inside the cone with apex P and axis cB: a sample s = cB + e, |e| <= |h|, makes an angle
     // with sin <= rho = |h| / |cB| with the axis, so tan <= rho / sqrt(1 - rho^2)
     const float cl2 = fmaf(cB0, cB0, fmaf(cB1, cB1, cB2 * cB2));
@@ -316,13 +324,16 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
     const float smaxv = (ax_len + __builtin_amdgcn_sqrtf(hh2) * 1.000001f) * (1.0f + 1e-6f);  // >= |sample| for every sample
     float l0 = 0.0f, l1 = 1.0f;
     // root box relative to P
-    clip_mul(l0, l1, -U0, -iU0, -((F.root_lo[0] - Pf0) - E)); clip_mul(l0, l1, L0, iL0, (F.root_hi[0] - Pf0) + E);
-    clip_mul(l0, l1, -U1, -iU1, -((F.root_lo[1] - Pf1) - E)); clip_mul(l0, l1, L1, iL1, (F.root_hi[1] - Pf1) + E);
-    clip_mul(l0, l1, -U2, -iU2, -((F.root_lo[2] - Pf2) - E)); clip_mul(l0, l1, L2, iL2, (F.root_hi[2] - Pf2) + E);
+    auto clip_root = [&]() {
+        clip_mul(l0, l1, -U0, -iU0, -((F.root_lo[0] - Pf0) - E)); clip_mul(l0, l1, L0, iL0, (F.root_hi[0] - Pf0) + E);
+        clip_mul(l0, l1, -U1, -iU1, -((F.root_lo[1] - Pf1) - E)); clip_mul(l0, l1, L1, iL1, (F.root_hi[1] - Pf1) + E);
+        clip_mul(l0, l1, -U2, -iU2, -((F.root_lo[2] - Pf2) - E)); clip_mul(l0, l1, L2, iL2, (F.root_hi[2] - Pf2) + E);
+    };
+    if (!TILES) clip_root();
     // The light's sample box is wider than it is far (a light of radius 10 inside a scene of extent 4: original.txt): the beam is
     // no beam, it meets everything near P - its rays are decided one by one, the walk below would only end in an overflow.
     const bool wide = rho2 > 1.0f;
-    const bool live = on && l0 <= l1;                // else: no pair here, or its beam misses the root box
+    const bool live = on && l0 <= l1;                // else: no pair here, or its beam misses the root box (tile beams: seen by the walk, if any)
     if (!TILES) {
         if (!live) return R;
         if (wide) { R.overflow = true; R.why = 1; return R; }
@@ -335,10 +346,10 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
         // lanes (one float4 each), distinct rows take turns.  The lane tests the row's primitives against its own beam with the
         // box and cone tests of the walk's leaf loop - no tree, no duplicates.  An overflowing row sends its lanes through the tree.
         use_walk = live && !wide && T->row == NONE;
-        const float m0 = fmaxf(l0 - 1e-6f, 0.0f), m1 = fminf(l1 + 1e-6f, 1.0f);
-        const float blo0 = fminf(m0 * L0, m1 * L0) - E, bhi0 = fmaxf(m0 * U0, m1 * U0) + E;
-        const float blo1 = fminf(m0 * L1, m1 * L1) - E, bhi1 = fmaxf(m0 * U1, m1 * U1) + E;
-        const float blo2 = fminf(m0 * L2, m1 * L2) - E, bhi2 = fmaxf(m0 * U2, m1 * U2) + E;
+        // the beam's box from P (lambda 0) to the samples (lambda 1), unclipped: what lies outside the root box holds no primitive
+        const float blo0 = fminf(0.0f, L0) - E, bhi0 = fmaxf(0.0f, U0) + E;
+        const float blo1 = fminf(0.0f, L1) - E, bhi1 = fmaxf(0.0f, U1) + E;
+        const float blo2 = fminf(0.0f, L2) - E, bhi2 = fmaxf(0.0f, U2) + E;
         bool pending = live && !wide && T->row != NONE;
         for (;;) {
             const unsigned long long pm = __ballot(pending);
@@ -405,6 +416,13 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
     // ---- phase 1: traversal.  The loops carry only the traversal state; a leaf entry that passes the float32
     // tests is parked (its primitive number, once) in the lane's LDS list tl[] (RT_TOUCH entries) and looked at
     // after the traversal.
+    RT_DIAG_ONLY(R.clk_rows = clock64();)
+    if (TILES && use_walk) {
+        iL0 = __builtin_amdgcn_rcpf(L0); iL1 = __builtin_amdgcn_rcpf(L1); iL2 = __builtin_amdgcn_rcpf(L2);
+        iU0 = __builtin_amdgcn_rcpf(U0); iU1 = __builtin_amdgcn_rcpf(U1); iU2 = __builtin_amdgcn_rcpf(U2);
+        clip_root();
+        use_walk = l0 <= l1;                         // else: the beam misses the root box
+    }
     if (use_walk) {
     uint32_t node = 0;
     int sp = 0;
@@ -522,6 +540,7 @@ __device__ __forceinline__ BeamOut beam_collect(const DScene &S, const FastScene
         unpack_lambda(t.y, l0, l1);
     }
     }
+    RT_DIAG_ONLY(R.clk_walk = clock64();)
     if (TILES) {
         if (!live) return R;
         if (wide) { R.overflow = true; R.why = 1; return R; }
