@@ -8,7 +8,8 @@ python - "$tag" <<'PY'
 import csv, glob, sys
 f = glob.glob("gpurun_out/tl_%s/*/*kernel_trace.csv" % sys.argv[1])[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-gens = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_gen") or r["Kernel_Name"].startswith("k_intersect_wide") or "ELb1EEv" in r["Kernel_Name"] or ("k_intersect<" in r["Kernel_Name"] and (", true, " in r["Kernel_Name"].split("(")[0] or r["Kernel_Name"].split("(")[0].endswith(", true>"))) or "k_small_level<true>" in r["Kernel_Name"]]
+import re
+gens = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_gen") or re.search(r"k_intersect<\w+, true", r["Kernel_Name"]) or "k_small_level<true>" in r["Kernel_Name"]]
 rows = rows[gens[-1]:]
 t0 = int(rows[0]["Start_Timestamp"])
 for r in rows:
