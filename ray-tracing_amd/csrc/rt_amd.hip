@@ -4,20 +4,20 @@
 // (ray_tracer.py:36-133) per iteration, no host synchronisation inside a frame:
 //
 //   per level:
-//     k_intersect  nearest hit of every queued ray, miss -> background, hit -> compacted hit list
-//                  (level 0 also makes the camera rays, 8x8 pixel tile per wave)    (ray_functions.py:7-43,
-//                                                                                BSPNode.py:123-210)
+//     k_intersect  nearest hit of every queued ray, miss -> background, hit -> compacted hit list; the hits'
+//                  reflection / transparency rays are appended to the next level's queue (parked per wave in LDS,
+//                  64 at a time); level 0 also makes the camera rays, 8x8 pixel tile per wave, zeroes the frame's
+//                  other framebuffers and writes the block boxes of the tile beams
+//                                                        (ray_functions.py:7-43, BSPNode.py:123-210, ray_tracer.py:108-130)
 //     soft shadows (Light.py:178-288), rt_shadow.hpp:
-//       k_block_box, k_bin_zone, k_bin_tiles   (level 0 of large frames) candidates per (8x8 pixel tile, light) by binning
+//       k_bin_zone, k_bin_tiles   (level 0 of large frames) candidates per (8x8 pixel tile, light) by binning
 //       k_beam_setup   one lane per (hit, light) pair: one beam traversal for all its s*s rays - or the tile's candidate
-//                      row filtered - and whole-pair verdicts
+//                      row filtered - and whole-pair verdicts; a pair that needs per-ray work takes a record slot
 //       k_shadow_beam  one lane per ray of the pairs that need it: float32 filtered predicates on the pair's candidates
 //       k_shadow_walk  rays of pairs with too many candidates: each walks the tree itself, same predicates
 //       k_shadow_queue what the filters could not decide, in float64
-//       (k_shadow_setup + k_shadow: one float64 decision per ray, the diagnostic / fallback path)
-//     k_shade      Phong terms, framebuffer accumulation, reflection / transparency rays appended to
-//                  the next level's queue with a wave-level prefix sum          (Light.py:35-175,
-//                                                                               ray_tracer.py:77-132)
+//       (k_shadow: one float64 decision per ray, the diagnostic / fallback path)
+//     k_shade      lit counts -> Phong terms, framebuffer accumulation               (Light.py:35-175, ray_tracer.py:77-106)
 //   k_resolve    clip + float32 / uint8 quantisation (k_accumulate: the same over K frames)
 //                                                                              (ray_tracer.py:30, util.py:98)
 // enqueue_levels() lays the levels out over four streams (level 0's shadows | nearest hits of levels 1.. | their

@@ -10,7 +10,7 @@
 //       and one has |tau_out| < 1e-6                           -> lit     ("AT_P": P's own surface)
 //
 // All s*s rays of one (hit, light) pair end in the same P and start inside one small box around the
-// light, so (1) ONE conservative beam traversal per pair (k_shadow_setup) collects the few
+// light, so (1) ONE conservative beam traversal per pair (k_beam_setup) collects the few
 // primitives any of its rays can touch, with their coordinates taken RELATIVE TO P in float64 and
 // only then rounded to float32 - the own surface sits at ~1e-16, not at an ulp of a world
 // coordinate; (2) each ray classifies those candidates in float32 with explicit error margins
