@@ -349,10 +349,15 @@ __device__ __forceinline__ bool ray_is_tame(d3 o, d3 d) {
 // diagnostics build only (make stats): per level [rays, node steps, leaf visits, leaf batches, confirmations, max node steps, max leaf visits, max confirmations]
 __device__ unsigned long long g_trav_stats[RT_MAX_LEVELS * 8];
 __device__ unsigned long long g_trav_time[RT_MAX_LEVELS * 8];     // per level: [7] = longest wave of k_intersect in wall_clock64 ticks (100 MHz)
+// one entry per wave of k_intersect (levels 0 - 15, first 4096 waves): clocks of the whole wave, inside its nearest-hit calls, and
+// of its busiest lane: descents, float32 leaf tests, confirmations, reference-order walk
+__device__ unsigned long long g_wave_log[16 * 4096 * 6];
+__device__ uint32_t g_wave_n[16];
 #endif
 // nearest hit, fast path with exact fallback (ties between different primitives, wild rays, non-kd trees)
 template <bool FAST>
-__device__ __forceinline__ Hit nearest_hit(const DScene &S, const FastScene &F, uint2 *stk, d3 o, d3 d, int stats_level = 0, const uint4 *ltop = nullptr) {
+__device__ __forceinline__ Hit nearest_hit(const DScene &S, const FastScene &F, uint2 *stk, d3 o, d3 d, int stats_level = 0, const uint4 *ltop = nullptr,
+                                           unsigned long long *wp = nullptr) {
     if (FAST && ray_is_tame(o, d)) {
         FastState st;
         fast_nearest<RT_BLOCK>(S, F, stk, o, d, __int_as_float(0x7f800000), -dinf(), st, ltop);
@@ -362,6 +367,9 @@ __device__ __forceinline__ Hit nearest_hit(const DScene &S, const FastScene &F, 
             atomicAdd(ts + 0, 1ull); atomicAdd(ts + 1, (unsigned long long)st.n_node); atomicAdd(ts + 2, (unsigned long long)st.n_leaf);
             atomicAdd(ts + 3, (unsigned long long)st.n_batch); atomicAdd(ts + 4, (unsigned long long)st.n_conf);
             atomicMax(ts + 5, (unsigned long long)st.n_node); atomicMax(ts + 6, (unsigned long long)st.n_leaf); atomicMax(ts + 7, (unsigned long long)st.n_conf);
+            unsigned long long *tt = g_trav_time + 8 * stats_level;      // [0..2]: clocks in descents / float32 leaf tests / confirmations, summed over rays
+            atomicAdd(tt + 0, st.c_desc); atomicAdd(tt + 1, st.c_test); atomicAdd(tt + 2, st.c_conf);
+            if (wp) { wp[0] += st.c_desc; wp[1] += st.c_test; wp[2] += st.c_conf; }
         }
 #endif
         if (!st.tie) {
@@ -370,6 +378,17 @@ __device__ __forceinline__ Hit nearest_hit(const DScene &S, const FastScene &F, 
             return st.best;
         }
     }
+#ifdef RT_TRAV_STATS
+    {
+        const unsigned long long e0 = clock64();
+        const Hit h = nearest_hit_exact(S, o, d);
+        unsigned long long *tt = g_trav_time + 8 * stats_level;      // [3]: clocks in the reference-order walk, [4]: rays that took it
+        const unsigned long long e1 = clock64();
+        atomicAdd(tt + 3, e1 - e0); atomicAdd(tt + 4, 1ull);
+        if (wp) wp[3] += e1 - e0;
+        return h;
+    }
+#endif
     return nearest_hit_exact(S, o, d);
 }
 
@@ -576,6 +595,8 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
     uint2 *stk = lds_stack + threadIdx.x;
 #ifdef RT_TRAV_STATS
     const long long tk0 = wall_clock64();
+    const unsigned long long tc_start = clock64();
+    unsigned long long wprof[4] = {0, 0, 0, 0}, tw_hit = 0;
 #endif
     if (frame_voided_uniform(&ctl->overflow)) return;       // a queue overflowed earlier in this frame: the frame is void
     // the first levels of the tree, in LDS behind the stacks (rt_fast.hpp)
@@ -639,12 +660,22 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
         // the nearest hit; hid: its id, hp: its point (also stored to the hit record as soon as it is known)
         int32_t hid = 0;
         d3 hp = mk3(dnan(), dnan(), dnan());
+#ifdef RT_TRAV_STATS
+        const unsigned long long th0 = clock64();
+#endif
         if (active) {
+#ifdef RT_TRAV_STATS
+            const Hit h = nearest_hit<FAST>(S, F, stk, o, d, lp.level, ltop, wprof);
+#else
             const Hit h = nearest_hit<FAST>(S, F, stk, o, d, lp.level, ltop);
+#endif
             hid = h.id;
             hp = h.p;
             if (hid != 0) { hb.px[k] = hp.x; hb.py[k] = hp.y; hb.pz[k] = hp.z; }
         }
+#ifdef RT_TRAV_STATS
+        tw_hit += clock64() - th0;
+#endif
         bool has_hit = false;
         uint32_t mflags = 0u;
         if (active) {
@@ -761,6 +792,19 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
     }
 #ifdef RT_TRAV_STATS
     if (lane == 0) atomicMax(g_trav_time + 8 * lp.level + 7, (unsigned long long)(wall_clock64() - tk0));
+    if (lp.level < 16) {
+        // the wave's busiest lane
+        unsigned long long mine = wprof[0] + wprof[1] + wprof[2] + wprof[3], best = mine;
+        for (int off = 32; off > 0; off >>= 1) { const unsigned long long o2 = __shfl_xor(best, off); best = o2 > best ? o2 : best; }
+        const unsigned long long who = __ballot(mine == best);
+        if (lane == __ffsll((long long)who) - 1 && tw_hit > 0) {
+            const uint32_t at = atomicAdd(&g_wave_n[lp.level], 1u);
+            if (at < 4096u) {
+                unsigned long long *e = g_wave_log + ((size_t)lp.level * 4096 + at) * 6;
+                e[0] = clock64() - tc_start; e[1] = tw_hit; e[2] = wprof[0]; e[3] = wprof[1]; e[4] = wprof[2]; e[5] = wprof[3];
+            }
+        }
+    }
 #endif
 }
 
@@ -2287,6 +2331,13 @@ extern "C" int rt_debug_trav_stats(unsigned long long *out, int n) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trav_stats), (size_t)n * sizeof(unsigned long long)) != hipSuccess) return RT_ERR_HIP;
     static unsigned long long zero[RT_MAX_LEVELS * 8];
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_trav_stats), zero, sizeof(zero)) != hipSuccess) return RT_ERR_HIP;
+    return RT_OK;
+}
+extern "C" int rt_debug_wave_log(unsigned long long *out, uint32_t *counts) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_log), sizeof(unsigned long long) * 16 * 4096 * 6) != hipSuccess) return RT_ERR_HIP;
+    if (hipMemcpyFromSymbol(counts, HIP_SYMBOL(g_wave_n), sizeof(uint32_t) * 16) != hipSuccess) return RT_ERR_HIP;
+    static const uint32_t zero[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_wave_n), zero, sizeof(zero)) != hipSuccess) return RT_ERR_HIP;
     return RT_OK;
 }
 extern "C" int rt_debug_trav_time(unsigned long long *out, int n) {

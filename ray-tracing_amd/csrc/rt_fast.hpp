@@ -89,6 +89,7 @@ __device__ __forceinline__ bool on_node_plane(const FastScene &F, int ax, float 
 #endif
 struct FastState {
     RT_TS(uint32_t n_node = 0; uint32_t n_leaf = 0; uint32_t n_batch = 0; uint32_t n_conf = 0;)
+    RT_TS(unsigned long long c_desc = 0; unsigned long long c_test = 0; unsigned long long c_conf = 0; unsigned long long c_pop = 0;)      // clocks: descents, float32 leaf tests, float64 confirmations, stack pops
     Hit best;
     bool tie;
     bool stop;       // shadow early-out taken
@@ -211,6 +212,7 @@ __device__ __forceinline__ void fast_tree(const DScene &S, const FastScene &F, u
     int sp = 0;
     for (;;) {
         KNode nd;
+        RT_TS(const unsigned long long tc0 = clock64();)
         // ---- descend to a leaf, near child first (the first levels from the LDS table) ----
         for (;;) {
             uint32_t ax, left, right;
@@ -241,6 +243,7 @@ __device__ __forceinline__ void fast_tree(const DScene &S, const FastScene &F, u
                 tmax = fminf(tmax, th);
             }
         }
+        RT_TS(const unsigned long long tc1 = clock64(); st.c_desc += tc1 - tc0; unsigned long long tcc = 0;)
         // ---- leaf ----
         {
             // four entries are requested together and rejected in float32 together: a leaf (<= 10 entries unless it
@@ -290,6 +293,7 @@ __device__ __forceinline__ void fast_tree(const DScene &S, const FastScene &F, u
                     }
                     if (cand && e0 + (uint32_t)k <= last) mask |= 1u << k;
                 }
+                RT_TS(const unsigned long long tc2 = clock64();)
                 while (mask) {
                     const int k = __builtin_ctz(mask);
                     mask &= mask - 1u;
@@ -306,8 +310,10 @@ __device__ __forceinline__ void fast_tree(const DScene &S, const FastScene &F, u
                     }
                     if (st.stop) return;
                 }
+                RT_TS(tcc += clock64() - tc2;)
             }
         }
+        RT_TS(const unsigned long long tc3 = clock64(); st.c_conf += tcc; st.c_test += (tc3 - tc1) - tcc;)
         // ---- next pending far node: it starts where the leaf just visited ended ----
         if (sp == 0) return;
         float prev = tmax;

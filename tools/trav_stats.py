@@ -31,8 +31,10 @@ def main():
         rc = lib.rt_debug_trav_stats(buf, 8 * 64)
         assert rc == 0
         print("level rays node/ray leaf/ray batch/ray conf/ray max_node max_leaf max_conf")
+        rays = {}
         for l in range(12):
             r = buf[8 * l]
+            rays[l] = r
             if not r:
                 continue
             print(l, r, *["%.2f" % (buf[8 * l + k] / r) for k in range(1, 5)], buf[8 * l + 5], buf[8 * l + 6], buf[8 * l + 7])
@@ -40,10 +42,28 @@ def main():
         if hasattr(lib, "rt_debug_trav_time"):
             rc = lib.rt_debug_trav_time(buf, 8 * 64)
             assert rc == 0
-            print("level: longest wave of k_intersect, us")
+            wave_log(lib)
+            print("level: longest wave of k_intersect, us | clocks per ray (as seen by the ray's lane, waiting for its wave included): descents, float32 leaf tests, float64 confirmations")
             for l in range(12):
                 if buf[8 * l + 7]:
-                    print(l, "%.1f" % (buf[8 * l + 7] / 100.0))
+                    r = max(rays.get(l, 1), 1)
+                    print(l, "%.1f" % (buf[8 * l + 7] / 100.0), "|", *["%.0f" % (buf[8 * l + k] / r) for k in range(3)], "| exact-walk rays %d, clocks each %.0f" % (buf[8 * l + 4], buf[8 * l + 3] / max(buf[8 * l + 4], 1)))
+
+
+def wave_log(lib):
+    """the slowest waves of every level: whole wave, inside nearest-hit calls, busiest lane's descents / leaf tests / confirmations / reference-order walk (clocks)"""
+    if not hasattr(lib, "rt_debug_wave_log"):
+        return
+    buf = (C.c_ulonglong * (16 * 4096 * 6))()
+    cnt = (C.c_uint32 * 16)()
+    assert lib.rt_debug_wave_log(buf, cnt) == 0
+    print("level: waves | median wave clocks | the three slowest waves: total, in nearest-hit calls, busiest lane: descents, leaf tests, confirmations, exact walk")
+    for l in range(16):
+        n = min(cnt[l], 4096)
+        if not n:
+            continue
+        rows = sorted((tuple(buf[(l * 4096 + i) * 6 + k] for k in range(6)) for i in range(n)), reverse=True)
+        print(l, n, "|", rows[n // 2][0], "|", *["%d/%d/%d+%d+%d+%d" % r for r in rows[:3]])
 
 
 if __name__ == "__main__":
