@@ -114,3 +114,32 @@ def test_batched_queries_on_torch_tensors_equal_the_host_buffer_forms(bench_ctx)
     assert 0.05 < lit_host.mean() < 0.99
     print("device queries, %d rays: nearest hit %.3f ms, any hit %.3f ms" % (n, e0.elapsed_time(e1), e1.elapsed_time(e2)))
     assert e0.elapsed_time(e2) < 20.0        # (a PCIe round trip of these buffers alone takes longer)
+
+
+def test_frames_enqueued_without_synchronisation_are_not_voided_by_their_pair_records():
+    """pool.txt at 1920x1080 with its own 5x5 shadow rays lists 41 % of its (hit, light) pairs, twice the share the record
+    slots start with.  The frames a caller synchronises on grow the records - the first by failing with
+    RT_ERR_QUEUE_OVERFLOW, a frame that fills more than 80 % of them without failing - so that a loop of frames with other
+    jitter seeds, enqueued back to back without rt_sync_stats (bench.py's timed loop), voids none of them."""
+    sys.path.insert(0, ROOT)
+    import bench
+    scene, _ = bench.build_scene("pool")
+    buf = torch.empty(1920 * 1080 * 3, dtype=torch.uint8, device="cuda:0")
+    with native.Context(scene.packed, device=0) as ctx:
+        ok = 0
+        for k in range(8):
+            try:
+                ctx.render_device(abi.render_params(1920, 1080, sh_rays=5, jitter=True, seed=1 + k), d_rgb8=buf.data_ptr())
+                ctx.sync_stats()
+                ok += 1
+                if ok == 2:
+                    break
+            except native.NativeError as e:
+                assert e.code == abi.RT_ERR_QUEUE_OVERFLOW
+        assert ok == 2
+        ctx.voided_frames(reset=True)
+        for k in range(24):
+            ctx.render_device(abi.render_params(1920, 1080, sh_rays=5, jitter=True, seed=100 + k), d_rgb8=buf.data_ptr())
+        st = ctx.sync_stats()
+        assert ctx.voided_frames(reset=True) == 0
+        assert st["shadow_rays"] == 350346000
