@@ -2,8 +2,9 @@
 rays, recursion 5, jitter on).  The reference cannot render it (memory), so parity at this size goes through
 properties that do not depend on the size:
 
-  * the oracle renders single ranks of a 48-way tile partition of the SAME frame (1/48 of the pixels, same jitter
-    hash): ids, ray counters and the 8-bit image of those tiles must agree with the GPU's;
+  * the oracle renders the whole frame once (all 2 M pixels, ~10 s of the box's host cores) and single ranks of a 48-way tile
+    partition of the SAME frame (1/48 of the pixels, same jitter hash): ids, ray counters and the 8-bit image must agree
+    with the GPU's;
   * the fast path (float32 culling, beam verdicts, filtered predicates, pipelined levels) must give the frame of the
     float64 reference-order walk, bit for bit;
   * the 8 ranks' tiles of a partitioned frame reassemble to the single-GPU frame, bit for bit.
@@ -57,6 +58,51 @@ def test_tiles_of_the_full_frame_match_the_oracle(bench_scene, full_frame, oracl
     idx = native.tile_layout(p)
     ok = idx >= 0
     assert np.array_equal(out["rgb8"].reshape(-1, 3)[ok], full_frame["rgb8"].reshape(-1, 3)[idx[ok]])
+
+
+def test_the_whole_full_size_frame_matches_the_oracle(bench_scene, full_frame, oracle):
+    """All 2 073 600 pixels of the bench frame (275.6 M rays) against the CPU oracle on the host's cores (~10 s on the GPU box's
+    16): ids bit-exact, 8-bit image within 1, every ray counter equal."""
+    scene, _ = bench_scene
+    ref = oracle.render(scene.packed, params(), threads=min(16, os.cpu_count() or 1), want_f64=False)
+    assert np.array_equal(full_frame["ids"], ref["ids"])
+    diff = np.abs(full_frame["rgb8"].astype(np.int16) - ref["rgb8"].astype(np.int16))
+    assert diff.max() <= 1
+    for key in ("primary_rays", "shadow_rays", "reflect_rays", "transmit_rays", "hits", "rays"):
+        assert full_frame["stats"][key] == ref["counters"][key], key
+    assert ref["counters"]["rays"] > 270_000_000
+
+
+def test_the_whole_3840x2160_frame_matches_the_oracle(bench_scene, oracle):
+    """BASELINE.json configs[3], what `bench.py --gpus N` splits over its ranks: 8.3 M pixels, 1.1 G rays, ~35 s of the box's host
+    cores for the oracle."""
+    scene, ctx = bench_scene
+    p = abi.render_params(3840, 2160, sh_rays=SH, rec_max=REC, jitter=True, seed=SEED)
+    out = ctx.render(p, want_rgb=False)
+    ref = oracle.render(scene.packed, p, threads=min(16, os.cpu_count() or 1), want_f64=False)
+    assert np.array_equal(out["ids"], ref["ids"])
+    assert np.abs(out["rgb8"].astype(np.int16) - ref["rgb8"].astype(np.int16)).max() <= 1
+    for key in ("primary_rays", "shadow_rays", "reflect_rays", "transmit_rays", "hits", "rays"):
+        assert out["stats"][key] == ref["counters"][key], key
+    assert ref["counters"]["rays"] > 1_000_000_000
+
+
+@pytest.mark.parametrize("workload,w,h", [("pool", 1920, 1080), ("original", 500, 500)])
+def test_whole_frames_of_the_reference_scenes_at_their_own_settings_match_the_oracle(oracle, workload, w, h):
+    """pool.txt (BASELINE.json configs[1]) and original.txt (configs[0]) with the shadow rays and recursion depth their files ask
+    for and hashed jitter: the frames `extra_frames` of the bench line times.  (The reference's own frames of these scenes, jitter
+    off, are in tests/test_gpu_parity.py.)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    scene, _ = bench.build_scene(workload)
+    p = abi.render_params(w, h, jitter=True, seed=77)
+    with native.Context(scene.packed, device=0) as ctx:
+        out = ctx.render(p, want_rgb=False)
+    ref = oracle.render(scene.packed, p, threads=min(16, os.cpu_count() or 1), want_f64=False)
+    assert np.array_equal(out["ids"], ref["ids"])
+    assert np.abs(out["rgb8"].astype(np.int16) - ref["rgb8"].astype(np.int16)).max() <= 1
+    for key in ("primary_rays", "shadow_rays", "reflect_rays", "transmit_rays", "hits", "rays"):
+        assert out["stats"][key] == ref["counters"][key], key
 
 
 def test_full_frame_equals_the_exact_walk(bench_scene, full_frame):
