@@ -241,6 +241,19 @@ def test_million_primitive_scene_full_frame_equals_float64_shadows(lattice_scene
     assert int((fast["rgb"] != exact["rgb"]).any(-1).sum()) == 0
 
 
+def test_million_primitive_scene_full_size_rank_matches_the_oracle(lattice_scene, oracle):
+    """... and one rank's share of that 1920x1080 frame (an eighth of its tiles, 38 M rays) against the CPU oracle."""
+    scene, ctx = lattice_scene
+    p = abi.render_params(1920, 1080, sh_rays=5, rec_max=10, jitter=True, seed=11, rank=5, world=8)
+    out = ctx.render(p, want_rgb=False)
+    ref = oracle.render(scene.packed, p, threads=min(16, os.cpu_count() or 1), want_f64=False)
+    assert np.array_equal(out["ids"], ref["ids"])
+    assert np.abs(out["rgb8"].astype(np.int16) - ref["rgb8"].astype(np.int16)).max() <= 1
+    for key in ("primary_rays", "shadow_rays", "reflect_rays", "transmit_rays", "hits", "rays"):
+        assert out["stats"][key] == ref["counters"][key], key
+    assert ref["counters"]["rays"] > 30_000_000
+
+
 def _workload_text(name):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import gen_scene
