@@ -1084,7 +1084,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
     if (lp.prio) __builtin_amdgcn_s_setprio(3);
     const uint32_t n_hits = min(ctl->n_hits[lp.level], lp.cap);
     const uint32_t nsl = (uint32_t)S.n_shadow_lights;
-    const uint32_t total = n_hits * nsl;           // < 2^32: checked on the host
+    // (n_hits * nsl < 2^28: checked on the host, enqueue_levels)
     const int lane = threadIdx.x & 63;
     // overflowing pairs are parked in a wave-private LDS buffer and get their list places 64 at a time (one returning
     // atomic on the counter per 64 pairs; see k_shadow_beam)
@@ -1098,7 +1098,6 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
     const uint32_t hit_blocks = (n_hits + 63u) >> 6;
     ChunkWalk walk((uint64_t)hit_blocks * nsl * 64u);
     uint64_t first;
-    (void)total;
     RT_DIAG_ONLY(unsigned long long bsum0 = 0, bsum1 = 0, bsum2 = 0, bsum3 = 0, bsum4 = 0, bsum5 = 0;)
     while (walk.next(first)) {
         RT_DIAG_ONLY(const unsigned long long bc0 = clock64(); unsigned long long bc1 = bc0, bc2 = bc0, bc3 = bc0, bc4 = bc0;)
