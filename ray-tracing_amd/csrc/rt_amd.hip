@@ -1345,7 +1345,7 @@ __device__ __forceinline__ bool shadow_ray_lit(const DScene &S, const FastScene 
         float tP = __double2float_ru(nv + RT_EPSILON);
         float tlim = fmaf(tP, RT_2M20, tP + 8e-6f);
         FastState st;
-        fast_nearest<RT_BLOCK>(S, F, stk, src, dir, tlim, nv - 3e-6, st);
+        fast_nearest<RT_BLOCK, true>(S, F, stk, src, dir, tlim, nv - 3e-6, st);      // (walked from P's end: the rays of a pair, neighbours in the wave, start in one leaf)
 #ifdef RT_DEBUG_BEAM
         if (lp.flags & 0x40000) printf("[exact] pair %llu sample %u lit %d stop %d nearest id %d dist %.17g nv %.17g src %.17g %.17g %.17g\n", (unsigned long long)seg, kk,
                                         (int)(!st.stop && (norm3(st.best.p - P) < RT_EPSILON)), (int)st.stop, st.best.id, st.best.dist, nv, src.x, src.y, src.z);

@@ -200,7 +200,11 @@ __device__ __forceinline__ bool fast_root_interval(const FastScene &F, const Fas
 // conservative interval meets the range is visited, and every primitive of a visited leaf is tested whole) -----------
 // early_dist: stop as soon as a confirmed hit is closer than this (-inf for ordinary rays).
 // stk: this lane's LDS stack column (stride STRIDE entries).
-template <int STRIDE>
+// REV: the far side of a cut first, the walk runs from the ray's END towards its origin.  The answer does not depend on the order
+// (every leaf that the segment can meet is visited, the float64 minimum is the same); for shadow rays, which start at a light
+// sample and end in the shaded point, it means that the rays of a (hit, light) pair - neighbours in a wave - start their walks
+// in the same leaf, at P, instead of in s*s leaves spread over the light, and an occluder near P ends them at once.
+template <int STRIDE, bool REV = false>
 __device__ __forceinline__ void fast_tree(const DScene &S, const FastScene &F, uint2 *stk, const FastRay &R, d3 o, d3 d, float tmin, float tmax,
                                           double early_dist, FastState &st, const uint4 *ltop = nullptr) {
     const float of0 = R.of0, of1 = R.of1, of2 = R.of2, ol0 = R.ol0, ol1 = R.ol1, ol2 = R.ol2;
@@ -236,11 +240,16 @@ __device__ __forceinline__ void fast_tree(const DScene &S, const FastScene &F, u
             const uint32_t nearc = dneg ? right : left, farc = dneg ? left : right;
             if (tl > tmax) node = nearc;                 // plane beyond the segment: near side only
             else if (th < tmin) node = farc;             // plane before the segment: far side only
-            else {                                       // both (NaN lands here too): far side waits on the stack
+            else if (!REV) {                             // both (NaN lands here too): far side waits on the stack
                 stk[sp * STRIDE] = make_uint2(farc, __float_as_uint(tmax));
                 ++sp;
                 node = nearc;
                 tmax = fminf(tmax, th);
+            } else {                                     // ... or the near side, with the start of the segment it will see
+                stk[sp * STRIDE] = make_uint2(nearc, __float_as_uint(tmin));
+                ++sp;
+                node = farc;
+                tmin = fmaxf(tmin, tl);
             }
         }
         RT_TS(const unsigned long long tc1 = clock64(); st.c_desc += tc1 - tc0; unsigned long long tcc = 0;)
@@ -316,19 +325,36 @@ __device__ __forceinline__ void fast_tree(const DScene &S, const FastScene &F, u
         RT_TS(const unsigned long long tc3 = clock64(); st.c_conf += tcc; st.c_test += (tc3 - tc1) - tcc;)
         // ---- next pending far node: it starts where the leaf just visited ended ----
         if (sp == 0) return;
-        float prev = tmax;
-        tmin = fmaxf(prev - fmaf(fabsf(prev), RT_2M19, 2.0f * Emax), 0.0f);
-        if (tmin > st.tbest) return;                     // everything still pending is farther than the best hit
-        --sp;
-        const uint2 top = stk[sp * STRIDE];
-        node = top.x;
-        tmax = fminf(__uint_as_float(top.y), st.tbest);
-        while (tmin > tmax) {                            // entry emptied by a better hit found meanwhile
-            if (sp == 0) return;
+        if (!REV) {
+            float prev = tmax;
+            tmin = fmaxf(prev - fmaf(fabsf(prev), RT_2M19, 2.0f * Emax), 0.0f);
+            if (tmin > st.tbest) return;                     // everything still pending is farther than the best hit
             --sp;
-            const uint2 t2 = stk[sp * STRIDE];
-            node = t2.x;
-            tmax = fminf(__uint_as_float(t2.y), st.tbest);
+            const uint2 top = stk[sp * STRIDE];
+            node = top.x;
+            tmax = fminf(__uint_as_float(top.y), st.tbest);
+            while (tmin > tmax) {                            // entry emptied by a better hit found meanwhile
+                if (sp == 0) return;
+                --sp;
+                const uint2 t2 = stk[sp * STRIDE];
+                node = t2.x;
+                tmax = fminf(__uint_as_float(t2.y), st.tbest);
+            }
+        } else {
+            // ... next pending NEAR node: it ends where the leaf just visited began (and never beyond the best hit)
+            float prev = tmin;
+            tmax = fminf(prev + fmaf(fabsf(prev), RT_2M19, 2.0f * Emax), st.tbest);
+            --sp;
+            const uint2 top = stk[sp * STRIDE];
+            node = top.x;
+            tmin = __uint_as_float(top.y);
+            while (tmin > tmax) {
+                if (sp == 0) return;
+                --sp;
+                const uint2 t2 = stk[sp * STRIDE];
+                node = t2.x;
+                tmin = __uint_as_float(t2.y);
+            }
         }
     }
 }
@@ -336,7 +362,7 @@ __device__ __forceinline__ void fast_tree(const DScene &S, const FastScene &F, u
 // o, d: the float64 ray.  tlim: float32 upper bound of the ray parameters that can matter
 // (+inf for ordinary rays).  early_dist: stop as soon as a confirmed hit is closer than this
 // (-inf for ordinary rays).  stk: this lane's LDS stack column (stride STRIDE entries).
-template <int STRIDE>
+template <int STRIDE, bool REV = false>
 __device__ __forceinline__ void fast_nearest(const DScene &S, const FastScene &F, uint2 *stk, d3 o, d3 d, float tlim,
                                              double early_dist, FastState &st, const uint4 *ltop = nullptr) {
     fast_init(st, tlim);
@@ -345,5 +371,5 @@ __device__ __forceinline__ void fast_nearest(const DScene &S, const FastScene &F
     if (st.stop) return;
     float tmin, tmax;
     if (!fast_root_interval(F, R, st.tbest, tmin, tmax)) return;
-    fast_tree<STRIDE>(S, F, stk, R, o, d, tmin, tmax, early_dist, st, ltop);
+    fast_tree<STRIDE, REV>(S, F, stk, R, o, d, tmin, tmax, early_dist, st, ltop);
 }
