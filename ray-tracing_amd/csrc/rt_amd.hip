@@ -377,6 +377,35 @@ __device__ __forceinline__ Hit nearest_hit(const DScene &S, const FastScene &F, 
                 st.best.p = mk3(RT_MAX_RENDER_DISTANCE, RT_MAX_RENDER_DISTANCE, RT_MAX_RENDER_DISTANCE);
             return st.best;
         }
+        // an exact tie between two primitives: the one the reference's walk visits first (FastScene::tie_off), without the walk
+        if (F.tie_off && !st.tie_many && st.best_prim >= 0 && st.tie_prim >= 0 &&
+            fmin(fmin(fabs(d.x), fabs(d.y)), fabs(d.z)) > 1e-200) {                 // (finite reciprocals: no 0 * inf in the slab tests)
+            const d3 inv = mk3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+            uint32_t fv[2] = {0xffffffffu, 0xffffffffu};
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const int32_t prim = w == 0 ? st.best_prim : st.tie_prim;
+                for (uint32_t k = F.tie_off[prim]; k < F.tie_off[prim + 1]; ++k) {
+                    const uint2 en = F.tie_ent[k];
+                    const DNode *nd = S.nodes + en.y;
+                    double tn;
+                    if (slab_exact(o, inv, nd->lo, nd->hi, false, tn)) { fv[w] = en.x; break; }
+                }
+            }
+            if (fv[0] != 0xffffffffu || fv[1] != 0xffffffffu) {
+                if (fv[0] <= fv[1]) return st.best;
+                const DPrim *pr = S.prims + st.tie_prim;
+                double t;
+                const bool hit = pr->kind == 1 ? sphere_exact(o, d, dot3(d, d), pr->a, pr->b[0], t) : slab_exact(o, inv, pr->a, pr->b, true, t);
+                if (hit) {
+                    Hit h;
+                    h.p = o + t * d;
+                    h.dist = norm3(h.p - o);
+                    h.id = pr->id;
+                    if (h.dist == st.best.dist) return h;
+                }
+            }
+        }
     }
 #ifdef RT_TRAV_STATS
     {
@@ -385,6 +414,7 @@ __device__ __forceinline__ Hit nearest_hit(const DScene &S, const FastScene &F, 
         unsigned long long *tt = g_trav_time + 8 * stats_level;      // [3]: clocks in the reference-order walk, [4]: rays that took it
         const unsigned long long e1 = clock64();
         atomicAdd(tt + 3, e1 - e0); atomicAdd(tt + 4, 1ull);
+        if (FAST && ray_is_tame(o, d)) atomicAdd(tt + 5, 1ull);      // [5]: ... of them because of an exact tie (the others: untame rays)
         if (wp) wp[3] += e1 - e0;
         return h;
     }
@@ -2657,6 +2687,34 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
         TRY_C(upload(ctx, ctx->scene_allocs, kn, &ctx->F.knodes));
         TRY_C(upload(ctx, ctx->scene_allocs, lf, &ctx->F.leaves));
         TRY_C(upload(ctx, ctx->scene_allocs, prim_entry, &ctx->F.prim_entry));
+        {
+            // leaf entries per primitive, ascending, with their leaf's node (FastScene::tie_off); only when the leaf list follows the
+            // nodes' pre-order, which is what "smaller entry = visited earlier" rests on
+            bool ordered = ok;
+            long long prev = -1;
+            for (int i = 0; i < nn && ordered; ++i)
+                if (s->node_right[i] < 0 && s->node_count[i] > 0) {
+                    if ((long long)s->node_first[i] <= prev) ordered = false;
+                    prev = (long long)s->node_first[i] + s->node_count[i] - 1;
+                }
+            ctx->F.tie_off = nullptr; ctx->F.tie_ent = nullptr;
+            if (ordered && ns + nb > 0) {
+                const size_t np = (size_t)ns + nb;
+                std::vector<uint32_t> off(np + 1, 0u);
+                for (int e = 0; e < s->n_leaf_refs; ++e) { const int p = s->leaf_prim[e]; if (p >= 0 && (size_t)p < np) ++off[p + 1]; }
+                for (size_t p = 0; p < np; ++p) off[p + 1] += off[p];
+                std::vector<uint2> ent(off[np]);
+                std::vector<uint32_t> fill(off.begin(), off.end() - 1);
+                for (int i = 0; i < nn; ++i)
+                    if (s->node_right[i] < 0)
+                        for (int e = s->node_first[i]; e < s->node_first[i] + s->node_count[i]; ++e) {
+                            const int p = s->leaf_prim[e];
+                            if (p >= 0 && (size_t)p < np) ent[fill[p]++] = make_uint2((uint32_t)e, (uint32_t)i);
+                        }
+                TRY_C(upload(ctx, ctx->scene_allocs, off, &ctx->F.tie_off));
+                TRY_C(upload(ctx, ctx->scene_allocs, ent, &ctx->F.tie_ent));
+            }
+        }
         float ext = 0;
         for (int k = 0; k < 3; ++k) {
             ctx->F.root_lo[k] = round_down(s->node_lo[k]);

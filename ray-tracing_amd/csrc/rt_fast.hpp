@@ -57,6 +57,13 @@ struct FastScene {
     // its first descent.  A ref with RT_TOP_FLAG is an index into this table, any other the node's index in knodes.
     const uint4 *top;
     int32_t n_top;                  // 0: no table
+    // Exact ties (two primitives at the same float64 distance: coplanar faces of touching boxes) go to the primitive the reference's
+    // walk visits FIRST.  For a tame ray the walk reaches a leaf exactly when the leaf's own box passes the slab test - an ancestor's
+    // box contains it bound for bound, and every step of the test (difference, product, minimum, maximum) is monotone in the bounds -
+    // and it visits leaf entries in the order of the leaf list.  So the winner is the tied primitive whose first leaf entry in a
+    // leaf that passes comes first: tie_ent[tie_off[p] .. tie_off[p + 1]) = {leaf entry, node} of primitive p, ascending.
+    const uint32_t *tie_off;        // nullptr: ties take the reference-order walk
+    const uint2 *tie_ent;
 };
 #define RT_TOP_FLAG 0x80000000u
 #define RT_TOP_MAX_NODES 255        // 8 levels, 4 KB of LDS per workgroup
@@ -91,6 +98,9 @@ struct FastState {
     RT_TS(uint32_t n_node = 0; uint32_t n_leaf = 0; uint32_t n_batch = 0; uint32_t n_conf = 0;)
     RT_TS(unsigned long long c_desc = 0; unsigned long long c_test = 0; unsigned long long c_conf = 0; unsigned long long c_pop = 0;)      // clocks: descents, float32 leaf tests, float64 confirmations, stack pops
     Hit best;
+    int32_t best_prim;       // primitive number of the best hit, -1: a plane (or none)
+    int32_t tie_prim;        // tie: the other primitive at the same distance
+    bool tie_many;           // ... and there is a third
     bool tie;
     bool stop;       // shadow early-out taken
     float tbest;     // float32 upper bound of the best hit's ray parameter
@@ -100,7 +110,7 @@ struct FastState {
 // hit point (ray_functions.py:61-77); the far clip of Background (Background.py:23) is applied
 // lazily - only hits farther than 1e8 can lose against it.
 __device__ __forceinline__ void fast_consider(const DScene &S, FastState &st, d3 o, d3 d, double t, int32_t id,
-                                              double early_dist) {
+                                              double early_dist, int32_t prim) {
     d3 p = o + t * d;
     if (nan3_any(p)) return;
     double dist = norm3(p - o);
@@ -112,12 +122,20 @@ __device__ __forceinline__ void fast_consider(const DScene &S, FastState &st, d3
         st.best.p = p;
         st.best.dist = dist;
         st.best.id = id;
+        st.best_prim = prim;
         st.tie = false;
+        st.tie_many = false;
         float tf = __double2float_ru(t);
         st.tbest = fmaf(fabsf(tf), RT_2M20, tf);
         if (dist < early_dist) st.stop = true;
     } else if (dist == st.best.dist && id != st.best.id) {
-        st.tie = true;
+        // (a plane that is the best hit stays: the reference looks at the planes before the tree and replaces a hit only by a
+        // strictly nearer one; the planes come first here as well, so a plane never ties with an earlier primitive)
+        if (st.best_prim >= 0) {
+            if (st.tie && prim != st.tie_prim) st.tie_many = true;
+            if (!st.tie) st.tie_prim = prim;
+            st.tie = true;
+        }
     }
 }
 
@@ -155,6 +173,9 @@ __device__ __forceinline__ void fast_init(FastState &st, float tlim) {
     st.best.dist = dinf();
     st.best.id = 0;
     st.tie = false;
+    st.tie_many = false;
+    st.best_prim = -1;
+    st.tie_prim = -1;
     st.stop = false;
     st.tbest = tlim;
 }
@@ -175,7 +196,7 @@ __device__ __forceinline__ void fast_planes(const DScene &S, const FastRay &R, d
             if (num + enum_ < rhs) continue;                       // certainly beyond the segment
         }
         double t;
-        if (plane_exact(o, d, pl, t)) fast_consider(S, st, o, d, t, pl.id, early_dist);
+        if (plane_exact(o, d, pl, t)) fast_consider(S, st, o, d, t, pl.id, early_dist, -1);
         if (st.stop) return;
     }
 }
@@ -312,10 +333,10 @@ __device__ __forceinline__ void fast_tree(const DScene &S, const FastScene &F, u
                     const DPrim *pr = S.prims + (pk >> 2);
                     double t;
                     if (kind == 1u) {
-                        if (sphere_exact(o, d, dot3(d, d), pr->a, pr->b[0], t)) fast_consider(S, st, o, d, t, pr->id, early_dist);
+                        if (sphere_exact(o, d, dot3(d, d), pr->a, pr->b[0], t)) fast_consider(S, st, o, d, t, pr->id, early_dist, (int32_t)(pk >> 2));
                     } else {
                         d3 inv = mk3(d.x != 0 ? 1.0 / d.x : dinf(), d.y != 0 ? 1.0 / d.y : dinf(), d.z != 0 ? 1.0 / d.z : dinf());
-                        if (slab_exact(o, inv, pr->a, pr->b, true, t)) fast_consider(S, st, o, d, t, pr->id, early_dist);
+                        if (slab_exact(o, inv, pr->a, pr->b, true, t)) fast_consider(S, st, o, d, t, pr->id, early_dist, (int32_t)(pk >> 2));
                     }
                     if (st.stop) return;
                 }

@@ -47,7 +47,7 @@ def main():
             for l in range(12):
                 if buf[8 * l + 7]:
                     r = max(rays.get(l, 1), 1)
-                    print(l, "%.1f" % (buf[8 * l + 7] / 100.0), "|", *["%.0f" % (buf[8 * l + k] / r) for k in range(3)], "| exact-walk rays %d, clocks each %.0f" % (buf[8 * l + 4], buf[8 * l + 3] / max(buf[8 * l + 4], 1)))
+                    print(l, "%.1f" % (buf[8 * l + 7] / 100.0), "|", *["%.0f" % (buf[8 * l + k] / r) for k in range(3)], "| exact-walk rays %d (%d ties), clocks each %.0f" % (buf[8 * l + 4], buf[8 * l + 5], buf[8 * l + 3] / max(buf[8 * l + 4], 1)))
 
 
 def wave_log(lib):
