@@ -243,6 +243,9 @@ int64_t rt_debug_alloc_calls(void);
 /* Diagnostic: frames of this context that took the tile beams (candidates per 8 x 8 pixel tile by binning, see RT_FLAG_NO_TILES),
  * counted when their counters are fetched (rt_sync_stats) and no queue overflow voided them. */
 int64_t rt_debug_tile_frames(const rt_ctx *ctx);
+/* Diagnostic: frames of this context whose camera pass was enqueued on the library's second stream, on the other copy of the
+ * level-0 state, so that it may run beside the tail of the frame before (frames back to back on one stream; rt_render_device). */
+int64_t rt_debug_early_frames(const rt_ctx *ctx);
 
 /*
  * Replaces ray_tracing(rays_sources, rays_directions, ...) (ray_tracer.py:36-133)

@@ -2227,6 +2227,7 @@ static BeamBuf *beam_set(FrameState &fs, int set) { BeamBuf *a[5] = {&fs.beam, &
 //   RT_AMD_BEAM_EARLY       0 | 1: beam walk near side first with the umbra test (default: scenes of >= 100 k primitives)
 //   RT_AMD_TILES_MIN(_PRIMS) tile beams for frames of at least this many camera rays / scenes of at least this many primitives
 //   RT_AMD_CREATE_THREADS   host threads of rt_create's table loops;  RT_AMD_PARSE_THREADS (rt_scene.cpp)
+//   RT_AMD_NO_EARLY_CAM     the camera pass of a frame waits for the end of the frame before it (AltL0 below)
 struct EnvCfg {
     long long walk_min = 3ll << 20;
     int beam_early = -1;
@@ -2234,7 +2235,9 @@ struct EnvCfg {
     long long tiles_min = 1500000;      // (the three small kernels in front of k_beam_setup cost more than they save on smaller frames)
     int tiles_min_prims = 256;          // (tile_scene_ok)
     bool debug = false;
+    bool no_early_cam = false;
     void read() {
+        no_early_cam = getenv("RT_AMD_NO_EARLY_CAM") != nullptr;
         if (const char *e = getenv("RT_AMD_WALK_MIN")) walk_min = atoll(e);
         if (const char *e = getenv("RT_AMD_BEAM_EARLY")) beam_early = atoi(e) != 0;
         no_pipeline = getenv("RT_AMD_NO_PIPELINE") != nullptr;
@@ -2243,6 +2246,25 @@ struct EnvCfg {
         debug = getenv("RT_AMD_DEBUG") != nullptr;
     }
 };
+// What a camera pass writes, a second time.  Frames enqueued back to back on one stream: the head of a frame is its camera pass -
+// a quarter of a millisecond with nothing beside it, everything else of the frame waits for its hits - and the tail is the float64
+// queue, the Phong kernel and the resolve of level 0, with a GPU that the deeper levels have already left.  With its own copy of
+// the level-0 state the camera pass of frame N + 1 runs beside the tail of frame N (on stream2, behind frame N's nearest-hit
+// chain); two copies alternate.  Everything a camera pass stores to is here: the camera rays' queue entries (origin and throughput
+// of camera rays are never stored: shared), the hit records and hit list of level 0 (the lit counters belong to the shadow
+// kernels: shared), the three framebuffers, the counter block, the tile beams' block boxes and zone counters, the append counters
+// of level 0's soft-shadow kernels.  The children go to q[1]: the pass waits for the last level of frame N that reads it.
+#define RT_EARLY_CAM_MAX_SLOTS 2200000ull
+struct AltL0 {
+    RayQ q0{};
+    HitBuf hb{};
+    double *fb = nullptr, *fb0 = nullptr, *fbm = nullptr;
+    FrameCtl *ctl = nullptr;
+    float *blockbox = nullptr;
+    uint32_t *zcnt = nullptr, *queue_n = nullptr;
+    bool ok = false, failed = false;
+};
+
 // workgroups per CU of the two sides of an overlapped frame (of a CU's four 128-register slots): level-0 side / deeper levels
 #define RT_OVL_MAIN 3
 #define RT_OVL_SIDE 1
@@ -2250,6 +2272,7 @@ struct EnvCfg {
 struct rt_ctx : FrameState {
     int device = 0;
     EnvCfg env;
+    int64_t early_frames = 0;               // frames enqueued with an early camera pass (rt_debug_early_frames)
     int64_t tile_frames = 0;                // frames rendered with tile beams whose counters were fetched and that no queue overflow voided (rt_debug_tile_frames)
     bool last_tiles = false;                // the last frame enqueued took the tile beams
     unsigned char *stage = nullptr;         // grow-only device staging for the blocking host-buffer entry points (no hipMalloc per call)
@@ -2284,6 +2307,15 @@ struct rt_ctx : FrameState {
     uint64_t acc_slots = 0;
     hipStream_t stream2 = nullptr;          // the deeper levels of an overlapped frame
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    AltL0 alt;                              // the other copy of the level-0 state (early camera pass)
+    std::vector<void *> alt_allocs;
+    uint64_t alt_bytes = 0;
+    int alt_cur = 0;                        // which of the two copies the context's own pointers name
+    hipEvent_t ev_cam = nullptr, ev_prev = nullptr, ev_end[2] = {nullptr, nullptr};   // camera pass done / stream order handed to stream2 / end of the last frame on copy 0, 1
+    bool ev_end_set[2] = {false, false};
+    bool early_prev = false;                // the last frame enqueued was a pipelined frame with an early camera pass ...
+    hipStream_t early_st = nullptr;         // ... on this stream,
+    int early_prev_rec = 0, early_prev_q1 = 0;   // ... with these levels: the last one / the last one that reads q[1]
     int nb_intersect = 1, nb_beam_setup = 1, nb_beam = 1, nb_queue = 1, nb_shade = 1, nb_setup = 1, nb_shadow = 1, nb_walk = 1;   // workgroups per CU
     int g_walk = 2048;
     int g_beam_setup_t = 2048, nb_beam_setup_t = 1;
@@ -2378,6 +2410,7 @@ extern "C" int rt_debug_trav_time(unsigned long long *out, int n) {
 }
 #endif
 extern "C" int64_t rt_debug_tile_frames(const rt_ctx *ctx) { return ctx ? ctx->tile_frames : 0; }
+extern "C" int64_t rt_debug_early_frames(const rt_ctx *ctx) { return ctx ? ctx->early_frames : 0; }
 extern "C" int64_t rt_noalloc_scratch_bytes(void) { return (int64_t)RT_SCRATCH_BYTES; }
 
 // host loops of rt_create over millions of independent records: cut into contiguous pieces, one thread each
@@ -2494,6 +2527,10 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
     HIP_C(hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
     HIP_C(rt_event_create(&ctx->ev_fork, false));
     HIP_C(rt_event_create(&ctx->ev_join, false));
+    HIP_C(rt_event_create(&ctx->ev_cam, false));
+    HIP_C(rt_event_create(&ctx->ev_prev, false));
+    HIP_C(rt_event_create(&ctx->ev_end[0], false));
+    HIP_C(rt_event_create(&ctx->ev_end[1], false));
     ctx->env.read();
     HIP_C(rt_malloc(&ctx->d_voided, sizeof(uint32_t)));
     HIP_C(hipMemset(ctx->d_voided, 0, sizeof(uint32_t)));
@@ -2867,6 +2904,12 @@ extern "C" int rt_create(const rt_scene_desc *s, int device, rt_ctx **out) {
 static void free_frame(rt_ctx *ctx) {
     for (void *p : ctx->frame_allocs) (void)hipFree(p);
     ctx->frame_allocs.clear();
+    for (void *p : ctx->alt_allocs) (void)hipFree(p);      // (whichever copy the context's pointers named: both are gone now)
+    ctx->alt_allocs.clear();
+    ctx->alt = AltL0{};
+    ctx->alt_bytes = 0;
+    ctx->early_prev = false;
+    ctx->ev_end_set[0] = ctx->ev_end_set[1] = false;
     FrameState empty;
     empty.ctl = ctx->ctl_own;
     static_cast<FrameState &>(*ctx) = empty;
@@ -2889,6 +2932,9 @@ extern "C" int rt_destroy(rt_ctx *ctx) {
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_cam) (void)hipEventDestroy(ctx->ev_cam);
+    if (ctx->ev_prev) (void)hipEventDestroy(ctx->ev_prev);
+    for (hipEvent_t e : ctx->ev_end) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_hit) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_lit) (void)hipEventDestroy(e);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -3218,8 +3264,78 @@ static int prof_bs_prepare(rt_ctx *ctx, int levels) {
 //     stream3 : for L = 1..rec, as soon as hits(L) are known: soft shadows(L) -> Phong(L) [adds into fb, in level order]
 // hits(L) reuses the buffer set and ray queue of level L-2 and waits for that level's shading.
 // fbm: where the rays of levels 1.. add the background when they miss (may be fb itself when nothing overlaps).
+// Which schedule a frame takes (one place: enqueue_frame decides about the early camera pass before enqueue_levels lays the
+// levels out).  own_fb0: level 0 has a framebuffer of its own (camera frames).
+struct Sched { bool fast, overlap, small, pipelined; };
+static Sched plan_schedule(const rt_ctx *ctx, const rt_render_params *p, int32_t sh, int32_t rec, bool own_fb0) {
+    Sched sc;
+    const bool prof = (p->flags & RT_FLAG_PROFILE) != 0;
+    const uint32_t s2 = (uint32_t)(sh * sh);
+    sc.fast = ctx->F.ok && !(p->flags & RT_FLAG_EXACT_TRAVERSAL);
+    sc.overlap = sc.fast && !prof && rec >= 1 && own_fb0 && ctx->two_sets && !(p->flags & RT_FLAG_NO_OVERLAP) && ctx->n_cu >= 8;
+    // small scene, few shadow rays per hit: one fused kernel per level over the LDS-resident scene (rt_small.hpp)
+    sc.small = ctx->small_ok && !prof && (s2 <= 4 || ctx->S.n_shadow_lights == 0) &&
+               !(p->flags & (RT_FLAG_EXACT_TRAVERSAL | RT_FLAG_NO_BEAM | RT_FLAG_NO_SMALL));
+    sc.pipelined = sc.overlap && !sc.small && ctx->three_sets && rec >= 2 && !ctx->env.no_pipeline;
+    return sc;
+}
+
+// the second copy of the level-0 state (AltL0), made when the first frame that can use it arrives; false: no memory for it
+static bool ensure_alt(rt_ctx *ctx) {
+    AltL0 &a = ctx->alt;
+    if (a.ok) return true;
+    if (a.failed || !ctx->cap || !ctx->fb_slots) return false;
+    uint64_t used = 0;
+    bool good = true;
+    auto get = [&](auto **pp, uint64_t n) {
+        if (!good) return;
+        const uint64_t bytes = ((n ? n : 1) * sizeof(**pp) + 255ull) & ~255ull;
+        void *v = nullptr;
+        if (rt_malloc(&v, bytes) != hipSuccess) { (void)hipGetLastError(); good = false; return; }
+        ctx->alt_allocs.push_back(v);
+        *pp = (decltype(*pp))v;
+        used += bytes;
+    };
+    const uint64_t cap = ctx->cap, nsl1 = (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1);
+    a.q0 = ctx->q[0];                        // origin and throughput of camera rays are never stored: shared
+    get(&a.q0.dx, cap); get(&a.q0.dy, cap); get(&a.q0.dz, cap);
+    get(&a.q0.slot, cap); get(&a.q0.gpix, cap); get(&a.q0.path, cap);
+    a.hb = ctx->hb;                          // lit counters: shared
+    get(&a.hb.px, cap); get(&a.hb.py, cap); get(&a.hb.pz, cap); get(&a.hb.id, cap); get(&a.hb.list, cap);
+    get(&a.fb0, ctx->fb_slots * 3); get(&a.fb, ctx->fb_slots * 3); get(&a.fbm, ctx->fb_slots * 3);
+    get(&a.ctl, 1);
+    get(&a.queue_n, 4);
+    if (ctx->beam.blockbox) { get(&a.blockbox, (uint64_t)ctx->tile_nblk * 8); get(&a.zcnt, (uint64_t)ctx->tile_nzone * nsl1); }
+    if (good) {
+        hipLaunchKernelGGL(k_init_beam_counters, dim3(1), dim3(64), 0, ctx->stream, a.queue_n, ctx->beam_queue_cap);
+        good = hipStreamSynchronize(ctx->stream) == hipSuccess;
+    }
+    if (!good) {
+        for (void *v : ctx->alt_allocs) (void)hipFree(v);
+        ctx->alt_allocs.clear();
+        a = AltL0{};
+        a.failed = true;                     // (until the frame state is carved again)
+        return false;
+    }
+    a.ok = true;
+    ctx->alt_bytes = used;
+    return true;
+}
+static void swap_alt(rt_ctx *ctx) {
+    AltL0 &a = ctx->alt;
+    std::swap(ctx->q[0].dx, a.q0.dx); std::swap(ctx->q[0].dy, a.q0.dy); std::swap(ctx->q[0].dz, a.q0.dz);
+    std::swap(ctx->q[0].slot, a.q0.slot); std::swap(ctx->q[0].gpix, a.q0.gpix); std::swap(ctx->q[0].path, a.q0.path);
+    std::swap(ctx->hb.px, a.hb.px); std::swap(ctx->hb.py, a.hb.py); std::swap(ctx->hb.pz, a.hb.pz);
+    std::swap(ctx->hb.id, a.hb.id); std::swap(ctx->hb.list, a.hb.list);
+    std::swap(ctx->fb, a.fb); std::swap(ctx->fb0, a.fb0); std::swap(ctx->fbm, a.fbm);
+    std::swap(ctx->ctl, a.ctl);
+    std::swap(ctx->beam.queue_n, a.queue_n);
+    std::swap(ctx->beam.blockbox, a.blockbox); std::swap(ctx->beam.zcnt, a.zcnt);
+    ctx->alt_cur ^= 1;
+}
+
 static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, int32_t rec, int32_t *d_ids, hipStream_t st,
-                          double *fb0, const GenParams *gen, double *fbm, const GenParams *cam) {
+                          double *fb0, const GenParams *gen, double *fbm, const GenParams *cam, bool early_cam = false) {
     LevelParams lp{};
     bool tiles = false;
     ctx->last_tiles = false;
@@ -3243,7 +3359,14 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
     dim3 block(RT_BLOCK);
     const bool prof = (p->flags & RT_FLAG_PROFILE) != 0;
     const bool time_bs = (prof || (p->flags & RT_FLAG_TIME_DOMINANT)) && ctx->prof_bs.size() >= 2 * (size_t)(rec + 1);
-    const bool fast = ctx->F.ok && !(p->flags & RT_FLAG_EXACT_TRAVERSAL);
+    const Sched sc = plan_schedule(ctx, p, sh, rec, fb0 != ctx->fb);
+    const bool fast = sc.fast;
+    // "the frame before was a pipelined frame on this stream": what an early camera pass and the deeper levels behind it may
+    // wait for level by level (ev_lit) instead of for everything enqueued so far.  Any other use of the frame state in between
+    // (a ray batch, a frame on another schedule) clears it.
+    const bool prev_pipelined = ctx->early_prev && ctx->early_st == st;
+    const int prev_rec = ctx->early_prev_rec;
+    ctx->early_prev = false;
     const uint32_t s2 = (uint32_t)(sh * sh);
     const bool beam = fast && ctx->S.n_planes <= RT_PMAX && !(p->flags & RT_FLAG_NO_BEAM) && s2 >= 9 && s2 <= RT_BLOCK &&
                       ctx->S.n_lights <= 256 &&   // pair record: 8-bit light index
@@ -3266,7 +3389,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
     // (ovl_main2) of a CU's 4 workgroup slots (amdgpu_waves_per_eu(4, 4), 256 threads each), the deeper levels ovl_side - together
     // never more than the slots there are, so that neither side ever waits for the other to retire (no kernel here spins on
     // another one's results, but a side that cannot get a slot runs after the other instead of beside it).
-    const bool overlap = fast && !prof && rec >= 1 && fb0 != ctx->fb && ctx->two_sets && !(p->flags & RT_FLAG_NO_OVERLAP) && ctx->n_cu >= 8;
+    const bool overlap = sc.overlap;
     const int ovl_main = RT_OVL_MAIN, ovl_side = RT_OVL_SIDE, ovl_main2 = RT_OVL_MAIN;      // (side 3: the level-0 kernels after the beam set-up; more of them per CU was measured: no gain)
     // grid of a kernel with nb workgroups per CU at full occupancy: side 0 = sequential, 1 = level-0 side, 2 = deeper levels
     auto gsz = [&](int full, int nb, int side) {
@@ -3348,8 +3471,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
 
     // Small scene, few shadow rays per hit: one fused kernel per level over the LDS-resident scene (rt_small.hpp).  The
     // diagnostic flags keep selecting the general pipeline, which the parity tests compare this path with.
-    const bool small = ctx->small_ok && !prof && (s2 <= 4 || ctx->S.n_shadow_lights == 0) &&
-                       !(p->flags & (RT_FLAG_EXACT_TRAVERSAL | RT_FLAG_NO_BEAM | RT_FLAG_NO_SMALL));
+    const bool small = sc.small;
     if (small) {
         static const GenParams none{};
         for (int level = 0; level <= rec; ++level) {
@@ -3385,9 +3507,21 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         }
     } else {
         hipStream_t s2_ = ctx->stream2;
-        intersect(0, st, ctx->q[0], ctx->q[1], ctx->hb, fb0, 0, ctx->beam);
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
-        HIP_TRY(ctx, hipStreamWaitEvent(s2_, ctx->ev_fork, 0));
+        if (early_cam) {
+            // the camera pass on stream2, behind the nearest-hit chain of the frame before and beside that frame's tail on st
+            // (enqueue_frame has ordered it behind what it overwrites)
+            // (three workgroups per CU, like the level-0 kernels it runs beside: with all four the last, small kernels of the
+            // frame before wait for a slot until the first workgroups of the pass retire - measured, 160 us for a 5 us kernel)
+            intersect(0, s2_, ctx->q[0], ctx->q[1], ctx->hb, fb0, 1, ctx->beam);
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_cam, s2_));
+            HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_cam, 0));
+            // the deeper levels' buffer sets and queues: the shading of the frame before is through with them
+            if (prev_pipelined) HIP_TRY(ctx, hipStreamWaitEvent(s2_, ctx->ev_lit[prev_rec], 0));
+        } else {
+            intersect(0, st, ctx->q[0], ctx->q[1], ctx->hb, fb0, 0, ctx->beam);
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
+            HIP_TRY(ctx, hipStreamWaitEvent(s2_, ctx->ev_fork, 0));
+        }
         // level 0 (caller's stream) is submitted first: the host needs ~10 us per launch, and the long chain of the
         // deeper levels must not delay the submission of the frame's largest kernel
         if (int rc = shadows(0, st, ctx->q[0], ctx->hb, ctx->beam, 1)) return rc;
@@ -3396,8 +3530,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
         // deeper levels (stream2): few, long rays - their waves ask for issue priority over the level-0 waves
         // (in frames of many million pixels the level-0 side is the long one and the priority only slows it down)
         lp.prio = ctx->fb_slots_frame <= (4u << 20) ? 1 : 0;
-        const bool no_pipe = ctx->env.no_pipeline;
-        if (ctx->three_sets && rec >= 2 && !no_pipe) {
+        if (sc.pipelined) {
             // Soft shadows of consecutive levels run side by side (odd levels on stream3, even levels on stream4: each is a latency
             // chain of its own); the Phong terms still reach fb in level order - shade(L) waits for shade(L - 1) - so the
             // float64 sums do not depend on the schedule.
@@ -3439,6 +3572,10 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
             }
             lp.prio = 0;
             HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_lit[rec], 0));      // shade(L) follows shade(L - 1): the last one covers all
+            if (gen) {
+                ctx->early_prev = true; ctx->early_st = st; ctx->early_prev_rec = rec;
+                ctx->early_prev_q1 = 1 + ((rec - 1) / (nd + 1)) * (nd + 1);     // the last level whose queue is q[1]
+            }
         } else {
             for (int level = 1; level <= rec; ++level) {
                 RayQ &qc = queue_of(level), &qn = queue_of(level + 1);
@@ -3481,7 +3618,32 @@ static int enqueue_frame(rt_ctx *ctx, const rt_render_params *p, const TileGeom 
     ctx->fb_slots_frame = g.slots;
     const GenParams gp = gen_params(ctx, g);
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->ctl, 0, sizeof(FrameCtl), st));
+    // Early camera pass (AltL0): a pipelined frame without primary ids (they are the caller's buffer, written by the pass) takes
+    // the other copy of the level-0 state, and its camera pass goes to stream2.
+    bool early_cam = false;
+    // Measured (tools/b2b.py, frames back to back): -4 to -6 % for frames of up to 2 M camera rays whose two sides end together
+    // (1280x720, a quarter or an eighth of 3840x2160, original.txt, pool.txt), -1 % at 1920x1080, +1 to +3 % from 4 M camera
+    // rays on (the pass of a large frame takes more from the tail it runs beside than it gains): a rule of the frame's size.
+    if (!prof && rec >= 2 && !d_ids && !ctx->env.no_early_cam && g.slots <= RT_EARLY_CAM_MAX_SLOTS) {
+        const Sched sc = plan_schedule(ctx, p, sh, rec, true);
+        if (sc.pipelined && ensure_alt(ctx)) early_cam = true;
+    }
+    hipStream_t s_head = st;
+    if (early_cam) {
+        swap_alt(ctx);
+        ++ctx->early_frames;
+        s_head = ctx->stream2;
+        // ... behind what it overwrites: this copy's last frame (its Phong kernel and resolve ran on that frame's stream),
+        if (ctx->ev_end_set[ctx->alt_cur]) HIP_TRY(ctx, hipStreamWaitEvent(s_head, ctx->ev_end[ctx->alt_cur], 0));
+        // and the readers of q[1], where the pass queues the children: the frame before, whose nearest-hit chain sits in front
+        // of the pass on stream2 anyway - its soft shadows and Phong kernels of the levels on q[1] do not
+        if (ctx->early_prev && ctx->early_st == st) HIP_TRY(ctx, hipStreamWaitEvent(s_head, ctx->ev_lit[ctx->early_prev_q1], 0));
+        else {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_prev, st));        // (no such frame: everything enqueued on st so far)
+            HIP_TRY(ctx, hipStreamWaitEvent(s_head, ctx->ev_prev, 0));
+        }
+    }
+    HIP_TRY(ctx, hipMemsetAsync(ctx->ctl, 0, sizeof(FrameCtl), s_head));
     if (prof) {      // otherwise k_intersect(0) initialises the framebuffers while it makes the camera rays
         HIP_TRY(ctx, hipMemsetAsync(ctx->fb, 0, g.out_slots * 3 * sizeof(double), st));
         HIP_TRY(ctx, hipMemsetAsync(ctx->fb0, 0, g.out_slots * 3 * sizeof(double), st));
@@ -3500,7 +3662,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_render_params *p, const TileGeom 
         PROF_MARK(0);
         if (prof) hipLaunchKernelGGL(k_gen, grid, block, 0, st, gp, ctx->q[0], ctx->ctl);
         PROF_MARK(1);
-        if (int rc = enqueue_levels(ctx, p, sh, rec, d_ids, st, ctx->fb0, prof ? nullptr : &gp, ctx->fbm, &gp)) return rc;
+        if (int rc = enqueue_levels(ctx, p, sh, rec, d_ids, st, ctx->fb0, prof ? nullptr : &gp, ctx->fbm, &gp, early_cam)) return rc;
     }
     PROF_MARK(2 + 6 * (rec + 1));
     if (d_rgb || d_rgb8) hipLaunchKernelGGL(k_resolve, grid, block, 0, st, ctx->fb, ctx->fb0, ctx->fbm, g.out_slots * 3, d_rgb, d_rgb8, ctx->ctl, ctx->d_voided);
@@ -3508,6 +3670,8 @@ static int enqueue_frame(rt_ctx *ctx, const rt_render_params *p, const TileGeom 
     PROF_MARK(3 + 6 * (rec + 1));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctl, ctx->ctl, sizeof(FrameCtl), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_end[ctx->alt_cur], st));      // (the copy of the level-0 state this frame ran on is free from here on)
+    ctx->ev_end_set[ctx->alt_cur] = true;
     HIP_TRY(ctx, hipGetLastError());
     ctx->frame_pending = true;
     ctx->last = *p; ctx->last_sh = sh; ctx->last_rec = rec; ctx->last_slots = g.slots; ctx->last_gen = true;
@@ -3718,7 +3882,7 @@ struct Stage {
     static size_t pad(size_t b) { return (b + 255) & ~(size_t)255; }
 };
 
-extern "C" int64_t rt_frame_bytes(const rt_ctx *ctx) { return ctx ? (int64_t)ctx->frame_bytes : -1; }
+extern "C" int64_t rt_frame_bytes(const rt_ctx *ctx) { return ctx ? (int64_t)(ctx->frame_bytes + ctx->alt_bytes) : -1; }
 
 extern "C" int rt_voided_frames(rt_ctx *ctx, int reset, int64_t *count) {
     if (!ctx || !count) return RT_ERR_INVALID_ARG;

@@ -17,7 +17,7 @@ _LIB = None
 
 EXPORTS = ("rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_tile_pixels", "rt_tile_layout",
            "rt_render", "rt_render_mean", "rt_render_device", "rt_render_device_noalloc", "rt_noalloc_scratch_bytes",
-           "rt_debug_alloc_calls", "rt_debug_tile_frames", "rt_sync_stats", "rt_voided_frames", "rt_frame_bytes", "rt_trace", "rt_intersect", "rt_visibility", "rt_intersect_device", "rt_visibility_device",
+           "rt_debug_alloc_calls", "rt_debug_tile_frames", "rt_debug_early_frames", "rt_sync_stats", "rt_voided_frames", "rt_frame_bytes", "rt_trace", "rt_intersect", "rt_visibility", "rt_intersect_device", "rt_visibility_device",
            "rt_deinterleave_u8",
            "rt_initial_rays", "rt_unit_prim_intersect", "rt_unit_prim_normals", "rt_unit_slab_mask",
            "rt_bsp_build", "rt_bsp_stats_get", "rt_bsp_fetch", "rt_bsp_destroy", "rt_bsp_last_error",
@@ -55,6 +55,8 @@ def lib():
         L.rt_debug_alloc_calls.restype = C.c_int64
         L.rt_debug_tile_frames.restype = C.c_int64
         L.rt_debug_tile_frames.argtypes = [C.c_void_p]
+        L.rt_debug_early_frames.restype = C.c_int64
+        L.rt_debug_early_frames.argtypes = [C.c_void_p]
         L.rt_sync_stats.argtypes = [C.c_void_p, C.POINTER(abi.Stats)]
         L.rt_frame_bytes.restype = C.c_int64
         L.rt_frame_bytes.argtypes = [C.c_void_p]

@@ -143,3 +143,54 @@ def test_frames_enqueued_without_synchronisation_are_not_voided_by_their_pair_re
         st = ctx.sync_stats()
         assert ctx.voided_frames(reset=True) == 0
         assert st["shadow_rays"] == 350346000
+
+
+@pytest.mark.parametrize("workload,w,h,kw", [
+    ("synth10k", 1920, 1080, dict(sh_rays=5, rec_max=5)),
+    ("synth10k", 3840, 2160, dict(sh_rays=5, rec_max=5, rank=3, world=8)),
+    ("synth10k", 317, 205, dict(sh_rays=3, rec_max=4)),
+    ("original", 500, 500, dict()),
+    ("pool", 640, 360, dict(sh_rays=5)),
+])
+def test_frames_in_flight_equal_frames_rendered_alone(workload, w, h, kw):
+    """Frames enqueued back to back on one stream: the camera pass of a frame runs on the library's second stream beside the
+    tail of the frame before, on the other copy of the level-0 state (rt_amd.hip: AltL0).  Every frame of such a run - other
+    jitter seeds, recursion depths that change from frame to frame - must equal the same frame rendered alone with its levels
+    in sequence, bit for bit (float32 of the float64 sums), and none may be voided."""
+    sys.path.insert(0, ROOT)
+    import bench
+    scene, _ = bench.build_scene(workload)
+    base = abi.render_params(w, h, **kw)
+    n = native.tile_pixels(base)
+    recs = [None, None, 2, None, 3, None, None, 2]        # None: the scene's / kw's own depth
+    st = torch.cuda.Stream()
+    with native.Context(scene.packed, device=0) as ctx:
+        def params(k, flags=0):
+            q = dict(kw)
+            if recs[k % len(recs)] is not None:
+                q["rec_max"] = recs[k % len(recs)]
+            return abi.render_params(w, h, jitter=True, seed=500 + k, flags=flags, **q)
+        # frames the caller synchronises on size the queues first
+        for k in range(4):
+            try:
+                ctx.render_device(params(0), d_rgb8=torch.empty(n * 3, dtype=torch.uint8, device="cuda:0").data_ptr())
+                ctx.sync_stats()
+                break
+            except native.NativeError as e:
+                assert e.code == abi.RT_ERR_QUEUE_OVERFLOW
+        ctx.voided_frames(reset=True)
+        for rounds in range(2):
+            K = 8
+            outs = [torch.full((n * 3,), -1.0, dtype=torch.float32, device="cuda:0") for _ in range(K)]
+            with torch.cuda.stream(st):
+                for k in range(K):
+                    ctx.render_device(params(k), d_rgb=outs[k].data_ptr(), stream=st.cuda_stream)
+            ctx.sync_stats()
+            torch.cuda.synchronize()
+            assert ctx.voided_frames(reset=True) == 0
+            assert native.lib().rt_debug_early_frames(ctx._h) >= (rounds + 1) * K      # (every frame of the run took the early pass)
+            for k in range(K):
+                ref = torch.full((n * 3,), -2.0, dtype=torch.float32, device="cuda:0")
+                ctx.render_device(params(k, flags=abi.RT_FLAG_NO_OVERLAP), d_rgb=ref.data_ptr())
+                ctx.sync_stats()
+                assert torch.equal(outs[k], ref), (workload, rounds, k)
