@@ -252,9 +252,10 @@ __device__ __forceinline__ bool ubeam_touch(const UBeam &B, const LeafF &lf) {
 // Within its XCD, workgroup j of nb takes the XCD's chunks j, j + nb, j + 2 nb, ...  Speed only, never correctness.
 #define RT_XCD_GROUP 8u
 struct ChunkWalk {
-    uint32_t m, step, xcd, nchunks;
-    __device__ ChunkWalk(uint64_t n_items) {
-        nchunks = (uint32_t)((n_items + RT_BLOCK - 1) / RT_BLOCK);
+    uint32_t m, step, xcd, nchunks, per;
+    __device__ ChunkWalk(uint64_t n_items, uint32_t per_chunk = RT_BLOCK) {      // per_chunk: items a workgroup takes at a time
+        per = per_chunk;
+        nchunks = (uint32_t)((n_items + per - 1) / per);
         xcd = blockIdx.x & 7u;
         m = blockIdx.x >> 3;                 // index among the XCD's chunks
         step = gridDim.x >> 3;               // workgroups per XCD (grids are multiples of 8)
@@ -263,7 +264,7 @@ struct ChunkWalk {
         const uint32_t c = ((m / RT_XCD_GROUP) * 8u + xcd) * RT_XCD_GROUP + (m % RT_XCD_GROUP);
         m += step;
         if (c >= nchunks) return false;      // c grows with m: nothing further either
-        first_item = (uint64_t)c * RT_BLOCK;
+        first_item = (uint64_t)c * per;
         return true;
     }
 };
@@ -1860,20 +1861,27 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, LevelParams lp, Ra
 // Framebuffers as in the general pipeline: fb <- shading (+ background the children of the last level would return),
 // fbm <- background of rays of levels >= 1 that miss.
 template <bool GEN>
-__global__ void __launch_bounds__(RT_BLOCK) k_small_level(DScene S, SmallLayout L, LevelParams lp, RayQ q, RayQ qn, FrameCtl *ctl, double *fb,
+__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) k_small_level(DScene S, SmallLayout L, LevelParams lp, RayQ q, RayQ qn, FrameCtl *ctl, double *fb,
                                                           double *fbm, double *fb_side, int32_t *ids_out, GenParams gp) {
     extern __shared__ uint2 lds_stack[];
     const LdsScene V = stage_scene(S, L, (RT_LDS unsigned char *)lds_stack);
     if (ctl->overflow) return;
     const uint32_t n = GEN ? gp.n_slots : min(ctl->n_rays[lp.level], lp.cap);
     if (GEN && blockIdx.x == 0 && threadIdx.x == 0) ctl->n_rays[0] = gp.n_slots;
-    ChunkWalk walk(n);
+    // Thin levels (a level of pool.txt from the fourth on holds a few thousand rays): the kernel's time is then ONE ray's chain -
+    // nearest hit, every light's shadow rays one after the other, Phong - in one lane of a nearly empty GPU.  With at most an
+    // eighth of the grid's lanes in rays, a ray takes eight lanes: all find its hit, lane m makes light m's shadow rays and
+    // Phong terms, and the terms are summed in light order (shuffles; the same float64 additions in the same order), the
+    // first lane of the eight writes.
+    const bool spread = !GEN && S.n_lights <= 8 && (uint64_t)n * 8u <= (uint64_t)gridDim.x * RT_BLOCK;
+    const uint32_t sub = spread ? (threadIdx.x & 7u) : 0u;
+    ChunkWalk walk(n, spread ? RT_BLOCK / 8 : RT_BLOCK);
     uint64_t first;
     const int lane = threadIdx.x & 63;
     unsigned long long valid_total = 0, n_refl = 0, n_trans = 0, n_hit = 0;
     const uint32_t s = (uint32_t)lp.sh_rays, s2 = s * s;
     while (walk.next(first)) {
-        const uint64_t k = first + threadIdx.x;
+        const uint64_t k = first + (spread ? (threadIdx.x >> 3) : threadIdx.x);
         bool active = k < n;
         uint32_t slot = RT_INVALID_SLOT, gpix = 0, path = 1u;
         d3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), thr = mk3(1.0, 1.0, 1.0);
@@ -1908,9 +1916,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_small_level(DScene S, SmallLayout 
             if (hit.id == 0) {
                 // ray_tracer.py:65,72,132: misses keep the background colour
                 if (GEN) { fb[3ull * slot] = S.bg[0]; fb[3ull * slot + 1] = S.bg[1]; fb[3ull * slot + 2] = S.bg[2]; }
-                else fb_add(fbm, slot, thr * ld3(S.bg));
+                else if (sub == 0u) fb_add(fbm, slot, thr * ld3(S.bg));
             } else {
-                n_hit++;
+                if (sub == 0u) n_hit++;
                 const d3 P = hit.p;
                 int32_t mi;
                 const d3 N = surface_normal_small(S, V, hit.id, P, mi);      // ray_tracer.py:77-78
@@ -1925,7 +1933,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_small_level(DScene S, SmallLayout 
                 const d3 Vv = neg3(d);
                 const d3 Nh = N / norm3(N);                                  // ray_functions.py:98-99
                 d3 diff = mk3(0, 0, 0), spec = mk3(0, 0, 0);
-                for (int m = 0; m < S.n_lights; ++m) {
+                for (int m = (int)sub; m < S.n_lights; m += spread ? 8 : 1) {
                     const DLight Lt = lds_load(V.lights + m);
                     const d3 dl = ld3(Lt.pos) - P;                           // Light.py:35-53
                     const d3 Ld = dl / norm3(dl);
@@ -1959,13 +1967,23 @@ __global__ void __launch_bounds__(RT_BLOCK) k_small_level(DScene S, SmallLayout 
                     double ldn = dot3(Ld, N);                                // Light.py:123-125
                     ldn = isnan(ldn) ? ldn : (ldn > 0 ? ldn : 0);
                     const d3 dterm = (ldn * Kd) * Imd;
-                    diff = (m == 0) ? dterm : diff + dterm;
+                    diff = (m == 0 || spread) ? dterm : diff + dterm;         // (spread: this lane's one light)
                     const double dp = dot3(Ld, Nh);                          // ray_functions.py:101-103
                     const d3 R = (2 * dp) * Nh - Ld;
                     const double rv = dot3(R, Vv);                           // Light.py:169
                     const double pw = ipow(rv, phong);
                     const d3 sterm = (pw * Ks) * Ims;                        // Light.py:171
-                    spec = (m == 0) ? sterm : spec + sterm;
+                    spec = (m == 0 || spread) ? sterm : spec + sterm;
+                }
+                if (spread) {
+                    const int g0 = lane & ~7;
+                    const d3 my_d = diff, my_s = spec;
+                    for (int m = 0; m < S.n_lights; ++m) {
+                        const d3 dt = mk3(__shfl(my_d.x, g0 + m), __shfl(my_d.y, g0 + m), __shfl(my_d.z, g0 + m));
+                        const d3 st = mk3(__shfl(my_s.x, g0 + m), __shfl(my_s.y, g0 + m), __shfl(my_s.z, g0 + m));
+                        diff = (m == 0) ? dt : diff + dt;
+                        spec = (m == 0) ? st : spec + st;
+                    }
                 }
                 spec = mk3(nan_to_num(spec.x), nan_to_num(spec.y), nan_to_num(spec.z));   // Light.py:173
                 const double nt = 1.0 - T;
@@ -1973,7 +1991,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_small_level(DScene S, SmallLayout 
                 if (GEN) {
                     const d3 v = thr * base;
                     fb[3ull * slot] = v.x; fb[3ull * slot + 1] = v.y; fb[3ull * slot + 2] = v.z;
-                } else fb_add(fb, slot, thr * base);
+                } else if (sub == 0u) fb_add(fb, slot, thr * base);
+                if (sub != 0u) mflags = 0;                                   // (children and their background: the first lane)
                 if (mflags & 1) {                                            // ray_tracer.py:108-116
                     thr_t = thr * mk3(T, T, T);
                     if (lp.last_level) fb_add(fb_children, slot, thr_t * ld3(S.bg));
@@ -2233,6 +2252,9 @@ struct EnvCfg {
     int beam_early = -1;
     bool no_pipeline = false;
     long long tiles_min = 1500000;      // (the three small kernels in front of k_beam_setup cost more than they save on smaller frames)
+    long long tiles_min_early = 400000; // ... unless the frame's camera pass ran early (AltL0): the other side of a small frame is shorter then, and the
+                                        // level-0 side decides - frames back to back, 400 k against 1.5 M: an eighth of 3840x2160 0.965 -> 0.933 ms,
+                                        // 1280x720 1.00 -> 0.92, 960x540 0.70 -> 0.67, 640x360 0.535 -> 0.536 (100 k: 0.563)
     int tiles_min_prims = 256;          // (tile_scene_ok)
     bool debug = false;
     bool no_early_cam = false;
@@ -2241,7 +2263,7 @@ struct EnvCfg {
         if (const char *e = getenv("RT_AMD_WALK_MIN")) walk_min = atoll(e);
         if (const char *e = getenv("RT_AMD_BEAM_EARLY")) beam_early = atoi(e) != 0;
         no_pipeline = getenv("RT_AMD_NO_PIPELINE") != nullptr;
-        if (const char *v = getenv("RT_AMD_TILES_MIN")) tiles_min = atoll(v);
+        if (const char *v = getenv("RT_AMD_TILES_MIN")) tiles_min = tiles_min_early = atoll(v);
         if (const char *v = getenv("RT_AMD_TILES_MIN_PRIMS")) tiles_min_prims = atoi(v);
         debug = getenv("RT_AMD_DEBUG") != nullptr;
     }
@@ -3373,7 +3395,7 @@ static int enqueue_levels(rt_ctx *ctx, const rt_render_params *p, int32_t sh, in
                       std::max(ctx->cap, ctx->cap_deep) * (uint64_t)(ctx->S.n_shadow_lights > 0 ? ctx->S.n_shadow_lights : 1) < (1ull << RT_LIST_NU_SHIFT);   // list entry: pair | units << 28
     // tile beams (level 0 of a camera frame in 8 x 8 tiles: the rays of a block of 64 slots are the pixels of a tile, their beams
     // towards a light nearly one beam); the binning buffers were carved for the frame sizes this context has seen
-    if (beam && cam && cam->tw * cam->th == 64 && (long long)cam->n_slots >= ctx->env.tiles_min && !lp.beam_early && !(p->flags & RT_FLAG_NO_TILES) && ctx->beam.trec != nullptr) {
+    if (beam && cam && cam->tw * cam->th == 64 && (long long)cam->n_slots >= (early_cam ? ctx->env.tiles_min_early : ctx->env.tiles_min) && !lp.beam_early && !(p->flags & RT_FLAG_NO_TILES) && ctx->beam.trec != nullptr) {
         lp.tile_stride = (uint32_t)std::max(1, (cam->tiles_x + cam->world / 2) / std::max(cam->world, 1));
         const TileGrid G(cam->n_slots, lp.tile_stride);
         tiles = G.nblk <= ctx->tile_nblk && G.nreg <= ctx->tile_nreg && G.nzone <= ctx->tile_nzone;
@@ -3624,7 +3646,11 @@ static int enqueue_frame(rt_ctx *ctx, const rt_render_params *p, const TileGeom 
     // Measured (tools/b2b.py, frames back to back): -4 to -6 % for frames of up to 2 M camera rays whose two sides end together
     // (1280x720, a quarter or an eighth of 3840x2160, original.txt, pool.txt), -1 % at 1920x1080, +1 to +3 % from 4 M camera
     // rays on (the pass of a large frame takes more from the tail it runs beside than it gains): a rule of the frame's size.
-    if (!prof && rec >= 2 && !d_ids && !ctx->env.no_early_cam && g.slots <= RT_EARLY_CAM_MAX_SLOTS) {
+    // Scenes of >= 100 k primitives keep the order "level 0's beam set-up takes the CUs first": their kernels are bound by
+    // the latency of a tree that misses L2, and the deeper levels started ahead of it thrash it (1 M lattice: 22.1 -> 25.7 ms).
+    // A frame enqueued while no other is pending (the caller has fetched the last one's status) has no tail to run beside
+    // and takes the plain order, its camera pass alone on all four workgroup slots of a CU.
+    if (!prof && rec >= 2 && !d_ids && !ctx->env.no_early_cam && g.slots <= RT_EARLY_CAM_MAX_SLOTS && ctx->S.n_prims < 100000 && ctx->frame_pending) {
         const Sched sc = plan_schedule(ctx, p, sh, rec, true);
         if (sc.pipelined && ensure_alt(ctx)) early_cam = true;
     }

@@ -490,7 +490,7 @@ def test_tile_beams_give_the_same_frames(gpu_ctx, kind, sh, jitter):
 
 
 def test_tile_beams_are_a_rule_of_scene_and_frame_size(gpu_ctx):
-    """Default thresholds: frames below 1.5 M camera rays and scenes below 256 primitives keep the pairs' own walks."""
+    """Default thresholds: frames below 1.5 M camera rays (400 k behind a pending frame) and scenes below 256 primitives keep the pairs' own walks."""
     ctx = gpu_ctx("synth400")
     before = native.lib().rt_debug_tile_frames(ctx._h)
     ctx.render(abi.render_params(320, 180, sh_rays=3, rec_max=1, jitter=True, seed=1))

@@ -32,6 +32,19 @@ def main():
         kw["sh_rays"] = a.sh_rays
     with native.Context(scene.packed) as ctx:
         ms = [bench.time_frames(ctx, abi, native, torch, stream, a.width, a.height, a.frames, 10, **kw) for _ in range(3)]
+        # host side: how long the calls of a frame take to return (the GPU idle, nothing to wait for)
+        import time
+        n = native.tile_pixels(abi.render_params(a.width, a.height, **kw))
+        buf = torch.empty(n * 3, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(stream):
+            for i in range(a.frames):
+                ctx.render_device(abi.render_params(a.width, a.height, seed=300 + i, **kw), d_rgb8=buf.data_ptr(), stream=stream.cuda_stream)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print("host: %.3f ms per frame to enqueue, %.3f ms per frame until the last one is done" % ((t1 - t0) * 1e3 / a.frames, (t2 - t0) * 1e3 / a.frames))
         print("b2b %s %dx%d world %d: ms per frame %s | frame state %.2f GB" % (a.workload, a.width, a.height, a.world, [round(m, 3) for m in ms], ctx.frame_bytes() / 1e9))
 
 
