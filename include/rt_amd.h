@@ -202,7 +202,10 @@ int rt_render_mean(rt_ctx *ctx, const rt_render_params *p, int32_t frames, float
 /* Same, outputs are DEVICE pointers on ctx's device (any may be NULL) and the
  * work is only enqueued on `stream` (a hipStream_t, NULL = the context's own
  * stream); nothing is synchronised.  Used by the bench and the multi-GPU gather.  Frames of one context share its
- * queues and framebuffers: enqueue them on ONE stream (they run back to back), use two contexts for two streams. */
+ * queues and framebuffers: enqueue them on ONE stream (they run back to back), use two contexts for two streams.
+ * A frame enqueued behind a frame that is still pending may start its camera pass beside that frame's last kernels (on a
+ * stream of the context, on a second copy of the level-0 state; frames without d_ids_out only): the outputs are written on
+ * `stream`, in call order, and every frame equals the frame rendered alone ("frames in flight"). */
 int rt_render_device(rt_ctx *ctx, const rt_render_params *p, float *d_rgb_out, uint8_t *d_rgb8_out,
                      int32_t *d_ids_out, void *stream);
 /* Wait for the context's stream and fetch the counters of the last frame. */

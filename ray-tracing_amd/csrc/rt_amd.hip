@@ -21,7 +21,8 @@
 //   k_resolve    clip + float32 / uint8 quantisation (k_accumulate: the same over K frames)
 //                                                                              (ray_tracer.py:30, util.py:98)
 // enqueue_levels() lays the levels out over four streams (level 0's shadows | nearest hits of levels 1.. | their
-// shadows and shading, odd and even levels apart); DESIGN.md section 5 and 8.
+// shadows and shading, odd and even levels apart); a frame enqueued behind a pending one starts with its camera pass on the
+// second of them, beside the tail of that frame (AltL0: a second copy of the level-0 state).  DESIGN.md section 5 and 8.
 //
 // The colour recursion  colour = through*T + (diff+spec)*(1-T) + refl*Kr  is linear in the child
 // colours, so each queued ray carries a throughput and adds throughput*local to its pixel.
