@@ -3651,7 +3651,14 @@ static int enqueue_frame(rt_ctx *ctx, const rt_render_params *p, const TileGeom 
     // the latency of a tree that misses L2, and the deeper levels started ahead of it thrash it (1 M lattice: 22.1 -> 25.7 ms).
     // A frame enqueued while no other is pending (the caller has fetched the last one's status) has no tail to run beside
     // and takes the plain order, its camera pass alone on all four workgroup slots of a CU.
-    if (!prof && rec >= 2 && !d_ids && !ctx->env.no_early_cam && g.slots <= RT_EARLY_CAM_MAX_SLOTS && ctx->S.n_prims < 100000 && ctx->frame_pending) {
+    // (pending: enqueued, status not fetched, and its last event not reached yet - a caller that synchronises the stream itself
+    // gets the plain order as well.  The choice is one of schedule only: the frames are the same either way.)
+    bool pending = false;
+    if (ctx->frame_pending) {
+        pending = hipEventQuery(ctx->ev1) == hipErrorNotReady;
+        (void)hipGetLastError();                                     // ("not ready" is an answer, not an error of this call)
+    }
+    if (!prof && rec >= 2 && !d_ids && !ctx->env.no_early_cam && g.slots <= RT_EARLY_CAM_MAX_SLOTS && ctx->S.n_prims < 100000 && pending) {
         const Sched sc = plan_schedule(ctx, p, sh, rec, true);
         if (sc.pipelined && ensure_alt(ctx)) early_cam = true;
     }
