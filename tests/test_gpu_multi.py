@@ -194,3 +194,65 @@ def test_frames_in_flight_equal_frames_rendered_alone(workload, w, h, kw):
                 ctx.render_device(params(k, flags=abi.RT_FLAG_NO_OVERLAP), d_rgb=ref.data_ptr())
                 ctx.sync_stats()
                 assert torch.equal(outs[k], ref), (workload, rounds, k)
+
+
+def test_mixed_calls_in_flight_equal_the_same_calls_alone(bench_ctx):
+    """What may sit between two frames in flight on one stream: a frame that asks for primary ids (plain order: the ids are the
+    caller's buffer), a batched query, a frame of another size, recursion depth or shadow-ray count, a frame with its levels
+    in sequence.  Everything is enqueued without a synchronisation in between and must equal the same call made alone."""
+    ctx = bench_ctx
+    ctx.sync_stats()
+    st = torch.cuda.Stream()
+    dev = "cuda:0"
+    calls = [  # (w, h, extra params, wants ids)
+        (640, 360, dict(sh_rays=5, rec_max=5, seed=1), False),
+        (640, 360, dict(sh_rays=5, rec_max=5, seed=2), True),
+        (640, 360, dict(sh_rays=5, rec_max=5, seed=3), False),
+        ("query",),
+        (320, 180, dict(sh_rays=5, rec_max=3, seed=4), False),
+        (640, 360, dict(sh_rays=2, rec_max=4, seed=5), False),
+        (640, 360, dict(sh_rays=5, rec_max=5, seed=6, flags=abi.RT_FLAG_NO_OVERLAP), False),
+        (640, 360, dict(sh_rays=5, rec_max=2, seed=7), False),
+        (200, 120, dict(sh_rays=3, rec_max=5, seed=8, rank=1, world=2), False),
+        (640, 360, dict(sh_rays=5, rec_max=5, seed=9), False),
+    ]
+    src, dirs = ctx.initial_rays(160, 90)
+    tO, tD = torch.from_numpy(src).to(dev), torch.from_numpy(dirs).to(dev)
+    nq = len(src)
+
+    def run(alone):
+        outs = []
+        with torch.cuda.stream(st):
+            for c in calls:
+                if c[0] == "query":
+                    pts = torch.full((nq, 3), -1.0, dtype=torch.float64, device=dev)
+                    ids = torch.full((nq,), -1, dtype=torch.int64, device=dev)
+                    ctx.intersect_device(tO.data_ptr(), tD.data_ptr(), nq, pts.data_ptr(), ids.data_ptr(), stream=st.cuda_stream)
+                    outs.append((pts, ids))
+                else:
+                    w, h, kw, want_ids = c
+                    p = abi.render_params(w, h, jitter=True, **kw)
+                    n = native.tile_pixels(p)
+                    rgb = torch.full((n * 3,), -1.0, dtype=torch.float32, device=dev)
+                    ids = torch.full((n,), -1, dtype=torch.int32, device=dev) if want_ids else None
+                    ctx.render_device(p, d_rgb=rgb.data_ptr(), d_ids=ids.data_ptr() if want_ids else 0, stream=st.cuda_stream)
+                    outs.append((rgb, ids))
+                if alone:
+                    st.synchronize()
+                    if c[0] != "query":
+                        ctx.sync_stats()
+        st.synchronize()
+        ctx.sync_stats()
+        return outs
+
+    run(alone=True)                         # (queues sized for every call of the list)
+    ctx.voided_frames(reset=True)
+    early0 = native.lib().rt_debug_early_frames(ctx._h)
+    flight = run(alone=False)
+    assert native.lib().rt_debug_early_frames(ctx._h) > early0
+    assert ctx.voided_frames(reset=True) == 0
+    alone = run(alone=True)
+    for k, (a, b) in enumerate(zip(flight, alone)):
+        for x, y in zip(a, b):
+            if x is not None:
+                assert torch.equal(x, y, ) if x.dtype != torch.float64 else bool(torch.all((x == y) | (torch.isnan(x) & torch.isnan(y)))), k
