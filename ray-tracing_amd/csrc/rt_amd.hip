@@ -2336,7 +2336,7 @@ struct rt_ctx : FrameState {
     int alt_cur = 0;                        // which of the two copies the context's own pointers name
     hipEvent_t ev_cam = nullptr, ev_prev = nullptr, ev_end[2] = {nullptr, nullptr};   // camera pass done / stream order handed to stream2 / end of the last frame on copy 0, 1
     bool ev_end_set[2] = {false, false};
-    bool early_prev = false;                // the last frame enqueued was a pipelined frame with an early camera pass ...
+    bool early_prev = false;                // the last use of the frame state was a pipelined camera frame (its levels recorded ev_lit) ...
     hipStream_t early_st = nullptr;         // ... on this stream,
     int early_prev_rec = 0, early_prev_q1 = 0;   // ... with these levels: the last one / the last one that reads q[1]
     int nb_intersect = 1, nb_beam_setup = 1, nb_beam = 1, nb_queue = 1, nb_shade = 1, nb_setup = 1, nb_shadow = 1, nb_walk = 1;   // workgroups per CU
