@@ -1,6 +1,8 @@
 """Random scene files with unusual proportions (tiny / huge lights, lights inside the field or grazing a plane, touching and
 overlapping primitives, 0-3 planes): the default path against the float64 reference-order walk, bit for bit.
-    python tools/fuzz_scenes.py [--n 60] [--seed 1]"""
+    python tools/fuzz_scenes.py [--n 60] [--seed 1] [--flight]
+--flight: besides, six frames of every scene enqueued back to back on one stream (other seeds, two frame sizes) against the
+same frames rendered alone with their levels in sequence (the early camera pass, rt_amd.hip: AltL0)."""
 import argparse
 import os
 import sys
@@ -75,8 +77,13 @@ def main():
     ap.add_argument("--n", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--dump", default="")
+    ap.add_argument("--flight", action="store_true")
     a = ap.parse_args()
     total = 0
+    early = 0
+    if a.flight:
+        import torch
+        stream = torch.cuda.Stream()
     for i in range(a.n):
         rng = np.random.default_rng(a.seed * 1000 + i)
         txt, sh = make_scene(rng)
@@ -95,6 +102,32 @@ def main():
         d2 = int((np.abs(nobeam["rgb"].astype(np.float64) - exact["rgb"].astype(np.float64)).max(-1) > 0).sum())
         di = int((fast["ids"] != exact["ids"]).sum())
         bad = d1 + d2 + di
+        if a.flight:
+            for (fw, fh) in ((200, 120), (331, 187)):
+                n = fw * fh
+                e0 = native.lib().rt_debug_early_frames(ctx._h)
+                outs = [torch.full((n * 3,), -1.0, dtype=torch.float32, device="cuda:0") for _ in range(6)]
+                with torch.cuda.stream(stream):
+                    for k in range(6):
+                        ctx.render_device(abi.render_params(fw, fh, jitter=True, seed=900 + k), d_rgb=outs[k].data_ptr(), stream=stream.cuda_stream)
+                try:
+                    ctx.sync_stats()
+                except native.NativeError as e:      # queues grew: once more
+                    with torch.cuda.stream(stream):
+                        for k in range(6):
+                            ctx.render_device(abi.render_params(fw, fh, jitter=True, seed=900 + k), d_rgb=outs[k].data_ptr(), stream=stream.cuda_stream)
+                    ctx.sync_stats()
+                torch.cuda.synchronize()
+                early += native.lib().rt_debug_early_frames(ctx._h) - e0
+                if ctx.voided_frames(reset=True):
+                    continue                             # (a voided frame wrote nothing: not the subject here)
+                for k in range(6):
+                    ref = torch.full((n * 3,), -2.0, dtype=torch.float32, device="cuda:0")
+                    ctx.render_device(abi.render_params(fw, fh, jitter=True, seed=900 + k, flags=abi.RT_FLAG_NO_OVERLAP), d_rgb=ref.data_ptr())
+                    ctx.sync_stats()
+                    if not torch.equal(outs[k], ref):
+                        bad += 1
+                        print("   frame in flight %d (%dx%d) differs from the frame alone" % (k, fw, fh), flush=True)
         total += bad
         d = sc.packed.desc
         print("scene %3d: prims %5d planes %d lights %d s %d | fast!=exact %d  nobeam!=exact %d  ids %d  rays %d%s" % (
@@ -103,6 +136,8 @@ def main():
             with open(os.path.join(a.dump, "fuzz_%d_%d.txt" % (a.seed, i)), "w") as f:
                 f.write(txt)
         ctx.close()
+    if a.flight:
+        print("frames that took the early camera pass:", early)
     print("TOTAL:", total)
     return 1 if total else 0
 
