@@ -22,6 +22,10 @@ def one(i):
     sc = FastScene(text=text)
     ctx = native.Context(sc.packed, device=0)
     out = ctx.render(abi.render_params(160 + i % 3 * 64, 90, jitter=True, seed=i))
+    for k in range(3):                      # frames in flight: the second copy of the level-0 state is made and freed too
+        ctx.render_device(abi.render_params(160, 90, jitter=True, seed=k))
+    ctx.sync_stats()
+    assert native.lib().rt_debug_early_frames(ctx._h) >= 1
     ctx.render_mean(abi.render_params(64, 48, jitter=True, seed=i), 3)
     o = np.random.default_rng(i).normal(size=(1000, 3)); d = np.random.default_rng(i + 1).normal(size=(1000, 3))
     ctx.intersect(o, d); ctx.visibility(o, d, o); ctx.trace(abi.render_params(1, 1, sh_rays=3, rec_max=2), o, d)
