@@ -64,6 +64,18 @@ int main(int argc, char **argv) {
             MUST(rt_render_mean(ctx, &p, 5, rgb.data(), rgb8.data(), &st));
             MUST_FAIL(rt_render_mean(ctx, &p, 0, rgb.data(), rgb8.data(), &st));
         }
+        {
+            // frames in flight (the early camera pass: a second copy of the level-0 state, made on the way, freed with the context;
+            // frame sizes that change re-carve the state while frames are pending)
+            const int sizes[4][2] = {{96, 64}, {96, 64}, {200, 120}, {64, 40}};
+            for (int round = 0; round < 2; ++round)
+                for (int k = 0; k < 8; ++k) {
+                    rt_render_params p = params(sizes[k % 4][0], sizes[k % 4][1], 5, 2 + k % 3, 1, 40 + k);
+                    MUST(rt_render_device(ctx, &p, nullptr, nullptr, nullptr, nullptr));
+                }
+            int rc = rt_sync_stats(ctx, &st);
+            if (rc != RT_OK && rc != RT_ERR_QUEUE_OVERFLOW) exit(5);
+        }
         // batched queries
         const int64_t n = 3001;
         std::vector<double> o((size_t)n * 3), dir((size_t)n * 3), tg((size_t)n * 3), pts((size_t)n * 3), col((size_t)n * 3);
